@@ -1,0 +1,130 @@
+// Goldilocks field (p = 2^64 - 2^32 + 1) and its quadratic extension for gfx950.
+//
+// Replaces plonky2_field 0.1.1 `GoldilocksField` / `QuadraticExtension`
+// (un-vendored dependency of the reference, /root/reference/Cargo.lock:2425-2427;
+// reached via `F = <C as GenericConfig<D>>::F`, eth-lc-plonky2/src/main.rs:74-76).
+//
+// Invariant: every value held between operations is CANONICAL (< p).  Inputs
+// that come from outside the library go through canon() once at load.
+// The header is plain C++ when not compiled by hipcc so that the kernel index
+// logic can be exercised by the CPU emulation harness in tests/emu/.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define LCP2_HD __host__ __device__ __forceinline__
+#else
+#define LCP2_HD inline
+#endif
+
+namespace lcp2 {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u64 GL_P = 0xFFFFFFFF00000001ull;
+constexpr u64 GL_EPS = 0xFFFFFFFFull;  // 2^64 mod p
+constexpr u64 GL_GENERATOR = 7;        // multiplicative generator = coset shift
+constexpr u64 GL_ROOT_2_32 = 1753635133440165772ull;
+constexpr u64 GL_W = 7;                // F_p[X]/(X^2 - 7)
+
+LCP2_HD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+
+LCP2_HD u64 gl_add(u64 a, u64 b) {
+  u64 s = a + b;
+  // a,b < p: at most one wrap; subtracting p modulo 2^64 is exact in both cases
+  return (s < a || s >= GL_P) ? s - GL_P : s;
+}
+LCP2_HD u64 gl_sub(u64 a, u64 b) {
+  u64 d = a - b;
+  return a < b ? d + GL_P : d;
+}
+LCP2_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+LCP2_HD u64 gl_dbl(u64 a) { return gl_add(a, a); }
+
+LCP2_HD void gl_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  lo = a * b;
+  hi = __umul64hi(a, b);
+#else
+  unsigned __int128 m = (unsigned __int128)a * b;
+  lo = (u64)m;
+  hi = (u64)(m >> 64);
+#endif
+}
+
+// x = lo + 2^64*hi ; 2^64 = 2^32-1, 2^96 = -1 (mod p).  Accepts any 128-bit x.
+LCP2_HD u64 gl_reduce128(u64 lo, u64 hi) {
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
+  u64 r = t0 + t1;
+  if (r < t0) r += GL_EPS;
+  return gl_canon(r);
+}
+LCP2_HD u64 gl_mul(u64 a, u64 b) {
+  u64 lo, hi;
+  gl_mul_wide(a, b, lo, hi);
+  return gl_reduce128(lo, hi);
+}
+LCP2_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+LCP2_HD u64 gl_pow(u64 b, u64 e) {
+  u64 r = 1;
+  while (e) {
+    if (e & 1) r = gl_mul(r, b);
+    b = gl_sqr(b);
+    e >>= 1;
+  }
+  return r;
+}
+LCP2_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+LCP2_HD u64 gl_root_of_unity(unsigned k) {
+  u64 r = GL_ROOT_2_32;
+  for (unsigned i = k; i < 32; i++) r = gl_sqr(r);
+  return r;
+}
+
+struct gl2 {
+  u64 c0, c1;
+};
+LCP2_HD gl2 gl2_make(u64 a, u64 b) { gl2 r; r.c0 = a; r.c1 = b; return r; }
+LCP2_HD gl2 gl2_add(gl2 a, gl2 b) { return gl2_make(gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)); }
+LCP2_HD gl2 gl2_sub(gl2 a, gl2 b) { return gl2_make(gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)); }
+LCP2_HD gl2 gl2_mul(gl2 a, gl2 b) {
+  u64 c0 = gl_add(gl_mul(a.c0, b.c0), gl_mul(GL_W, gl_mul(a.c1, b.c1)));
+  u64 c1 = gl_add(gl_mul(a.c0, b.c1), gl_mul(a.c1, b.c0));
+  return gl2_make(c0, c1);
+}
+LCP2_HD gl2 gl2_scale(gl2 a, u64 s) { return gl2_make(gl_mul(a.c0, s), gl_mul(a.c1, s)); }
+LCP2_HD gl2 gl2_add_base(gl2 a, u64 b) { return gl2_make(gl_add(a.c0, b), a.c1); }
+LCP2_HD gl2 gl2_sub_base(gl2 a, u64 b) { return gl2_make(gl_sub(a.c0, b), a.c1); }
+LCP2_HD bool gl2_eq(gl2 a, gl2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+LCP2_HD gl2 gl2_inv(gl2 a) {
+  u64 n = gl_sub(gl_sqr(a.c0), gl_mul(GL_W, gl_sqr(a.c1)));
+  u64 ni = gl_inv(n);
+  return gl2_make(gl_mul(a.c0, ni), gl_mul(gl_neg(a.c1), ni));
+}
+LCP2_HD gl2 gl2_pow(gl2 b, u64 e) {
+  gl2 r = gl2_make(1, 0);
+  while (e) {
+    if (e & 1) r = gl2_mul(r, b);
+    b = gl2_mul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+
+LCP2_HD u32 bitrev32(u32 x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+  u32 r = 0;
+  for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+#endif
+}
+
+}  // namespace lcp2

@@ -1,0 +1,163 @@
+// Host-side orchestration of the multi-pass NTT: table construction (tiny, done
+// once per size on the host and uploaded) and the pass schedule.  Templated on a
+// backend so that the HIP library and the CPU emulation harness (tests/emu) run
+// the same schedule:
+//   const u64* Backend::table(const std::string& key, std::function<std::vector<u64>()> make)
+//   void Backend::launch_pass(bool inverse, const NttPassParams&, u32 wgs, u32 cols, u32 z)
+//   void Backend::launch_bitrev(const BitrevTile&, u32 wgs, u32 cols)      (lg >= 12)
+//   void Backend::launch_bitrev_small(in, out, strides, lg, cols)          (lg < 12)
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+#include "ntt.hpp"
+
+namespace lcp2 {
+
+inline std::vector<u64> make_pow_table(u64 base, u64 first, size_t count, u64 scalar = 1) {
+  // out[j] = scalar * base^(first * j)
+  std::vector<u64> t(count);
+  u64 step = gl_pow(base, first), cur = scalar;
+  for (size_t j = 0; j < count; j++) { t[j] = cur; cur = gl_mul(cur, step); }
+  return t;
+}
+
+template <class Backend>
+struct NttHost {
+  Backend &be;
+  explicit NttHost(Backend &b) : be(b) {}
+
+  static std::string key(const char *what, u64 a, u64 b, u64 c = 0) {
+    return std::string(what) + ":" + std::to_string(a) + ":" + std::to_string(b) + ":" + std::to_string(c);
+  }
+
+  const u64 *stage_table(u32 B, bool inv) {
+    if (B == 0) B = 1;
+    return be.table(key("stage", B, inv), [=] {
+      u64 w = gl_root_of_unity(B);
+      if (inv) w = gl_inv(w);
+      return make_pow_table(w, 1, B > 1 ? (size_t)1 << (B - 1) : 1);
+    });
+  }
+  TwoLevelTable root_table(u32 lg, bool inv) {
+    TwoLevelTable t;
+    t.h = (lg + 1) / 2;
+    u32 h = t.h;
+    t.lo = be.table(key("rootlo", lg, inv), [=] {
+      u64 w = gl_root_of_unity(lg);
+      if (inv) w = gl_inv(w);
+      return make_pow_table(w, 1, (size_t)1 << h);
+    });
+    t.hi = be.table(key("roothi", lg, inv), [=] {
+      u64 w = gl_root_of_unity(lg);
+      if (inv) w = gl_inv(w);
+      return make_pow_table(w, 1ull << h, (size_t)1 << (lg - h));
+    });
+    return t;
+  }
+  // shift_z^j tables for z = 0..nz-1, shift_z = base * w_{2^(lg+zbits)}^z  (z = 0 only when zbits = 0);
+  // inverse: (shift^-1)^j scaled by `scalar`.
+  TwoLevelTable shift_table(u64 base, u32 lg, u32 zbits, bool inv, u64 scalar, u64 &lo_stride, u64 &hi_stride) {
+    TwoLevelTable t;
+    t.h = (lg + 1) / 2;
+    u32 h = t.h;
+    u32 nz = 1u << zbits;
+    lo_stride = (u64)1 << h;
+    hi_stride = (u64)1 << (lg - h);
+    auto shift_of = [=](u32 z) {
+      u64 s = base;
+      if (zbits) s = gl_mul(s, gl_pow(gl_root_of_unity(lg + zbits), z));
+      return inv ? gl_inv(s) : s;
+    };
+    t.lo = be.table(key("shlo", base, lg * 64 + zbits * 2 + inv, scalar), [=] {
+      std::vector<u64> all;
+      for (u32 z = 0; z < nz; z++) {
+        auto v = make_pow_table(shift_of(z), 1, (size_t)1 << h);
+        all.insert(all.end(), v.begin(), v.end());
+      }
+      return all;
+    });
+    t.hi = be.table(key("shhi", base, lg * 64 + zbits * 2 + inv, scalar), [=] {
+      std::vector<u64> all;
+      for (u32 z = 0; z < nz; z++) {
+        auto v = make_pow_table(shift_of(z), 1ull << h, (size_t)1 << (lg - h), scalar);
+        all.insert(all.end(), v.begin(), v.end());
+      }
+      return all;
+    });
+    return t;
+  }
+
+  // Forward coset NTT, natural in -> bit-reversed out.
+  //   zbits = 0: one transform of size 2^lg per column, out[col] has 2^lg elements.
+  //   zbits = r: low-degree extension: 2^r coset transforms of the same 2^lg coefficients,
+  //              coset z (shift * w_{2^(lg+r)}^z) lands in block bitrev(z) of out[col] (2^(lg+r) elements),
+  //              i.e. out is the bit-reversed order of the size-2^(lg+r) coset NTT of the zero-padded input.
+  // shift = 1 and zbits = 0 gives the plain NTT (no scaling pass).
+  void forward(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols, u64 shift, u32 zbits) {
+    NttGroup groups[8];
+    int ng = ntt_plan(lg, groups);
+    for (int gi = 0; gi < ng; gi++) {
+      const NttGroup &g = groups[gi];
+      NttPassParams p{};
+      bool first = gi == 0;
+      p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
+      p.stage_tw = stage_table(g.B, false);
+      if (g.g_lo) p.tw = root_table(g.g_lo + g.B, false);
+      u32 wgs, nz;
+      if (first) {
+        p.in = in; p.in_col_stride = in_col_stride; p.in_z_stride = 0;
+        p.out = out; p.out_col_stride = out_col_stride; p.out_z_stride = (u64)1 << lg; p.zbits = zbits;
+        if (shift != 1 || zbits) {
+          p.scale_mode = 2;
+          p.sc = shift_table(shift, lg, zbits, false, 1, p.sc_lo_z_stride, p.sc_hi_z_stride);
+        }
+        wgs = 1u << (lg - g.L);
+        nz = 1u << zbits;
+      } else {
+        // remaining groups: in place over the whole out column (all coset blocks are just more sub-transforms)
+        p.in = out; p.in_col_stride = out_col_stride;
+        p.out = out; p.out_col_stride = out_col_stride;
+        wgs = 1u << (lg + zbits - g.L);
+        nz = 1;
+      }
+      be.launch_pass(false, p, wgs, ncols, nz);
+    }
+  }
+
+  // Inverse coset NTT, bit-reversed in -> natural out, includes 1/n and shift^-j.
+  void inverse_bitrev_in(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols, u64 shift) {
+    NttGroup groups[8];
+    int ng = ntt_plan(lg, groups);
+    u64 ninv = gl_inv(((u64)1 << lg) % GL_P);
+    for (int gi = ng - 1; gi >= 0; gi--) {
+      const NttGroup &g = groups[gi];
+      NttPassParams p{};
+      p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
+      p.stage_tw = stage_table(g.B, true);
+      if (g.g_lo) p.tw = root_table(g.g_lo + g.B, true);
+      bool firstpass = gi == ng - 1, lastpass = gi == 0;
+      p.in = firstpass ? in : out; p.in_col_stride = firstpass ? in_col_stride : out_col_stride;
+      p.out = out; p.out_col_stride = out_col_stride;
+      if (lastpass) {
+        if (shift == 1) { p.scale_mode = 1; p.scale_scalar = ninv; }
+        else { p.scale_mode = 2; p.sc = shift_table(shift, lg, 0, true, ninv, p.sc_lo_z_stride, p.sc_hi_z_stride); }
+      }
+      be.launch_pass(true, p, 1u << (lg - g.L), ncols, 1);
+    }
+  }
+
+  // ifft of natural-order values -> natural-order coefficients (PolynomialValues::ifft):
+  // bit-reversal permutation into `out`, then the in-place inverse passes.
+  void inverse_natural(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols) {
+    if (lg >= 12) {
+      BitrevTile b{in, out, in_col_stride, out_col_stride, lg};
+      be.launch_bitrev(b, 1u << (lg - 12), ncols);
+    } else {
+      be.launch_bitrev_small(in, in_col_stride, out, out_col_stride, lg, ncols);
+    }
+    inverse_bitrev_in(out, out_col_stride, out, out_col_stride, lg, ncols, 1);
+  }
+};
+
+}  // namespace lcp2

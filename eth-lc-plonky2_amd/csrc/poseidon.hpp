@@ -1,0 +1,145 @@
+// Poseidon-12 over Goldilocks (x^7, 4 + 22 + 4 rounds), one permutation per lane.
+//
+// Replaces plonky2 0.1.4 hash/poseidon.rs + poseidon_goldilocks.rs
+// (`PoseidonPermutation`, `PoseidonHash::{hash_no_pad, two_to_one, hash_or_noop}`;
+// un-vendored dependency, /root/reference/Cargo.lock:2347-2350; reached through
+// `PoseidonGoldilocksConfig`, eth-lc-plonky2/src/main.rs:75).
+//
+// The state lives in 24 VGPRs of one lane; round constants are wave-uniform
+// (scalar loads from the constant segment).  The MDS layer uses the fact that
+// every matrix entry is < 64: the state is split into 32-bit halves, each half
+// is accumulated in 64 bits (v_mad_u64_u32) and the two partial sums are folded
+// with a single Goldilocks reduction per output lane.
+#pragma once
+#include "gl64.hpp"
+
+namespace lcp2 {
+
+constexpr int POS_W = 12;
+constexpr int POS_RATE = 8;
+constexpr int POS_FULL_HALF = 4;
+constexpr int POS_PARTIAL = 22;
+constexpr int POS_ROUNDS = 30;
+
+LCP2_HD u64 pos_sbox(u64 x) {
+  u64 x2 = gl_sqr(x);
+  u64 x4 = gl_sqr(x2);
+  u64 x3 = gl_mul(x, x2);
+  return gl_mul(x3, x4);
+}
+
+// fold lo + hi * 2^32 (lo, hi < 2^42) into one canonical field element
+LCP2_HD u64 pos_fold(u64 lo, u64 hi) {
+  u64 hi_hi = hi >> 32;          // < 2^10
+  u64 hi_lo = hi & GL_EPS;
+  u64 t = lo + ((hi_hi << 32) - hi_hi);  // + hi_hi * (2^64 mod p), no overflow
+  u64 u = hi_lo << 32;
+  u64 r = t + u;
+  if (r < t) r += GL_EPS;
+  return gl_canon(r);
+}
+
+#define LCP2_MDS_C0 17
+#define LCP2_MDS_C1 15
+#define LCP2_MDS_C2 41
+#define LCP2_MDS_C3 16
+#define LCP2_MDS_C4 2
+#define LCP2_MDS_C5 28
+#define LCP2_MDS_C6 13
+#define LCP2_MDS_C7 13
+#define LCP2_MDS_C8 39
+#define LCP2_MDS_C9 18
+#define LCP2_MDS_C10 34
+#define LCP2_MDS_C11 20
+
+// out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  DIAG = [8, 0, ...]
+LCP2_HD void pos_mds(u64 s[12]) {
+  const u32 C[12] = {LCP2_MDS_C0, LCP2_MDS_C1, LCP2_MDS_C2, LCP2_MDS_C3, LCP2_MDS_C4, LCP2_MDS_C5,
+                     LCP2_MDS_C6, LCP2_MDS_C7, LCP2_MDS_C8, LCP2_MDS_C9, LCP2_MDS_C10, LCP2_MDS_C11};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      al += (u64)lo[(i + r) % 12] * C[i];
+      ah += (u64)hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
+    s[r] = pos_fold(al, ah);
+  }
+}
+
+// rc: 30 * 12 round constants, canonical.  s: canonical in, canonical out.
+LCP2_HD void pos_permute(u64 s[12], const u64 *__restrict__ rc) {
+  int round = 0;
+#pragma unroll 1
+  for (int r = 0; r < POS_FULL_HALF; r++, round++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add(s[i], rc[round * 12 + i]));
+    pos_mds(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < POS_PARTIAL; r++, round++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], rc[round * 12 + i]);
+    s[0] = pos_sbox(s[0]);
+    pos_mds(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < POS_FULL_HALF; r++, round++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add(s[i], rc[round * 12 + i]));
+    pos_mds(s);
+  }
+}
+
+// ---- round-constant derivation (host side; uploaded to the device once) ----
+// ChaCha8Rng::seed_from_u64(0) sampled with rand-0.8 uniform [0, p): SURVEY App. A.3.
+inline void pos_derive_round_constants(u64 out[POS_ROUNDS * POS_W]) {
+  auto rotl = [](u32 x, int r) { return (u32)((x << r) | (x >> (32 - r))); };
+  u32 key[8];
+  u64 st = 0;
+  for (int i = 0; i < 8; i++) {
+    st = st * 6364136223846793005ull + 11634580027462260723ull;
+    u32 xs = (u32)(((st >> 18) ^ st) >> 27);
+    int rot = (int)(st >> 59);
+    key[i] = rot ? (u32)((xs >> rot) | (xs << (32 - rot))) : xs;
+  }
+  u32 blk[16];
+  int pos = 16, got = 0;
+  u64 ctr = 0;
+  while (got < POS_ROUNDS * POS_W) {
+    u32 w[2];
+    for (int k = 0; k < 2; k++) {
+      if (pos == 16) {
+        u32 in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        for (int i = 0; i < 8; i++) in[4 + i] = key[i];
+        in[12] = (u32)ctr; in[13] = (u32)(ctr >> 32); in[14] = 0; in[15] = 0;
+        ctr++;
+        u32 x[16];
+        for (int i = 0; i < 16; i++) x[i] = in[i];
+        auto qr = [&](int a, int b, int c, int d) {
+          x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16);
+          x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12);
+          x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);
+          x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+        };
+        for (int r = 0; r < 4; r++) {
+          qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+          qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) blk[i] = x[i] + in[i];
+        pos = 0;
+      }
+      w[k] = blk[pos++];
+    }
+    u64 v = (u64)w[0] | ((u64)w[1] << 32);
+    unsigned __int128 m = (unsigned __int128)v * GL_P;
+    if ((u64)m <= 0xFFFFFFFF00000000ull) out[got++] = (u64)(m >> 64);
+  }
+}
+
+}  // namespace lcp2

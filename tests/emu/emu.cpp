@@ -1,0 +1,75 @@
+// TEST HARNESS (not product code): runs the portable load/stage/store phases of the
+// device kernels on the CPU, thread by thread, so that index logic and field
+// arithmetic of csrc/*.hpp can be checked against the oracle without a GPU.
+// Built by tests/emu_lib.py with g++; never loaded by the package.
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+#include "../../eth-lc-plonky2_amd/csrc/poseidon.hpp"
+#include "../../eth-lc-plonky2_amd/csrc/ntt_host.hpp"
+
+using namespace lcp2;
+
+struct EmuBackend {
+  std::map<std::string, std::vector<u64>> tabs;
+  const u64 *table(const std::string &k, std::function<std::vector<u64>()> make) {
+    auto it = tabs.find(k);
+    if (it == tabs.end()) it = tabs.emplace(k, make()).first;
+    return it->second.data();
+  }
+  void launch_pass(bool inv, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
+    NttPass pass{p};
+    std::vector<u64> lds((size_t)1 << p.L);
+    const u32 T = NTT_THREADS;
+    for (u32 z = 0; z < nz; z++)
+      for (u32 c = 0; c < cols; c++)
+        for (u32 w = 0; w < wgs; w++) {
+          for (u32 t = 0; t < T; t++) inv ? pass.load<true>(lds.data(), t, T, w, c, z) : pass.load<false>(lds.data(), t, T, w, c, z);
+          if (!inv) {
+            for (int b = (int)(p.S + p.B) - 1; b >= (int)p.S; b--)
+              for (u32 t = 0; t < T; t++) pass.stage<false>(lds.data(), t, T, (u32)b);
+          } else {
+            for (u32 b = p.S; b < p.S + p.B; b++)
+              for (u32 t = 0; t < T; t++) pass.stage<true>(lds.data(), t, T, b);
+          }
+          for (u32 t = 0; t < T; t++) inv ? pass.store<true>(lds.data(), t, T, w, c, z) : pass.store<false>(lds.data(), t, T, w, c, z);
+        }
+  }
+  void launch_bitrev(const BitrevTile &b, u32 wgs, u32 cols) {
+    std::vector<u64> lds(64 * 65);
+    for (u32 c = 0; c < cols; c++)
+      for (u32 w = 0; w < wgs; w++) {
+        for (u32 t = 0; t < 256; t++) b.load(lds.data(), t, 256, w, c);
+        for (u32 t = 0; t < 256; t++) b.store(lds.data(), t, 256, w, c);
+      }
+  }
+  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
+    for (u32 c = 0; c < cols; c++)
+      for (u32 i = 0; i < (1u << lg); i++) out[c * os + bitrev32(i, lg)] = gl_canon(in[c * is + i]);
+  }
+};
+
+static u64 g_rc[360];
+static bool g_rc_ok = false;
+
+extern "C" {
+void emu_poseidon_permute(u64 *s) {
+  if (!g_rc_ok) { pos_derive_round_constants(g_rc); g_rc_ok = true; }
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+  pos_permute(s, g_rc);
+}
+u64 emu_gl_mul(u64 a, u64 b) { return gl_mul(gl_canon(a), gl_canon(b)); }
+void emu_ntt_forward(const u64 *in, u64 *out, u32 lg, u32 ncols, u64 shift, u32 zbits) {
+  EmuBackend be; NttHost<EmuBackend> h(be);
+  h.forward(in, (u64)1 << lg, out, (u64)1 << (lg + zbits), lg, ncols, shift, zbits);
+}
+void emu_ntt_inverse_natural(const u64 *in, u64 *out, u32 lg, u32 ncols) {
+  EmuBackend be; NttHost<EmuBackend> h(be);
+  h.inverse_natural(in, (u64)1 << lg, out, (u64)1 << lg, lg, ncols);
+}
+void emu_ntt_inverse_bitrev(const u64 *in, u64 *out, u32 lg, u32 ncols, u64 shift) {
+  EmuBackend be; NttHost<EmuBackend> h(be);
+  h.inverse_bitrev_in(in, (u64)1 << lg, out, (u64)1 << lg, lg, ncols, shift);
+}
+}
