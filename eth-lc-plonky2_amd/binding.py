@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI declared in include/lcp2.h.
+
+This is the same shape of stub a Rust `plonky2` fork would write with `extern "C"`
+(see INTEGRATION.md); Python is used here only because the image has no Rust
+toolchain.  There is no CPU fallback: if liblcp2.so is missing or no HIP device
+is usable, calls raise `Lcp2Error`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u8p = ctypes.POINTER(ctypes.c_uint8)
+MEM_HOST, MEM_DEVICE = 0, 1
+
+K_INTT, K_LDE, K_LEAF_HASH, K_MERKLE, K_PERM_Z, K_QUOTIENT, K_OPENINGS, K_FRI, K_POW, K_SHA256, K_OTHER = range(11)
+KERNEL_FAMILIES = ["intt", "lde", "leaf_hash", "merkle", "perm_z", "quotient", "openings", "fri", "pow", "sha256", "other"]
+
+GOLDILOCKS_P = 0xFFFFFFFF00000001
+
+
+class Lcp2Error(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"lcp2 status {status}: {message}")
+        self.status = status
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        "degree_bits", "num_wires", "num_routed_wires", "num_constants", "rate_bits", "cap_height",
+        "num_challenges", "quotient_degree_factor", "proof_of_work_bits", "num_query_rounds", "num_fri_layers")]
+    _fields_.append(("fri_arity_bits", ctypes.c_uint32 * 8))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads (building if the sources are newer) eth-lc-plonky2_amd/liblcp2.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        path = _build.build_native()
+    lib = ctypes.CDLL(path)
+    c = ctypes
+    sigs = {
+        "lcp2_status_str": (c.c_char_p, [c.c_int]),
+        "lcp2_abi_version": (c.c_int, []),
+        "lcp2_device_count": (c.c_int, []),
+        "lcp2_params_standard": (c.c_int, [c.c_uint32, c.c_uint32, c.POINTER(Params)]),
+        "lcp2_ctx_create": (c.c_int, [c.c_int, c.c_void_p, c.POINTER(c.c_void_p)]),
+        "lcp2_ctx_destroy": (None, [c.c_void_p]),
+        "lcp2_ctx_sync": (c.c_int, [c.c_void_p]),
+        "lcp2_last_error": (c.c_char_p, [c.c_void_p]),
+        "lcp2_poseidon_permute_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]),
+        "lcp2_merkle_cap": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_uint32, c.c_int, c.c_void_p]),
+        "lcp2_ntt_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int, c.c_uint64, c.c_int]),
+        "lcp2_lde_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_int]),
+        "lcp2_sha256_tree": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint32, c.c_size_t, c.c_void_p, c.c_void_p, c.c_int]),
+        "lcp2_commit_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
+        "lcp2_commit_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
+        "lcp2_oracle_destroy": (None, [c.c_void_p]),
+        "lcp2_oracle_open": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]),
+        "lcp2_oracle_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
+        "lcp2_prof_reset": (c.c_int, [c.c_void_p]),
+        "lcp2_prof_get": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_uint64), c.POINTER(c.c_double)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what lcp2.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = None  # filled by tests from include/lcp2.h
+
+
+def _np_u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def standard_params(degree_bits, num_constants=4):
+    lib = load_library()
+    p = Params()
+    rc = lib.lcp2_params_standard(degree_bits, num_constants, ctypes.byref(p))
+    if rc:
+        raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+    return p
+
+
+class Oracle:
+    """PolynomialBatch handle (device resident)."""
+
+    def __init__(self, ctx, handle, ncols, log_n, rate_bits, cap_height, cap):
+        self.ctx, self.handle = ctx, handle
+        self.ncols, self.log_n, self.rate_bits, self.cap_height = ncols, log_n, rate_bits, cap_height
+        self.cap = cap
+
+    def open(self, indices):
+        idx = _np_u64(indices)
+        k = idx.size
+        nsib = self.log_n + self.rate_bits - self.cap_height
+        leaves = np.zeros((k, self.ncols), dtype=np.uint64)
+        sib = np.zeros((k, max(nsib, 0), 4), dtype=np.uint64)
+        self.ctx._check(self.ctx.lib.lcp2_oracle_open(self.handle, _ptr(idx), k, _ptr(leaves), _ptr(sib)))
+        return leaves, sib
+
+    def read(self, coeffs=True, lde=True):
+        n = 1 << self.log_n
+        c = np.zeros((self.ncols, n), dtype=np.uint64) if coeffs else None
+        l = np.zeros((self.ncols, n << self.rate_bits), dtype=np.uint64) if lde else None
+        self.ctx._check(self.ctx.lib.lcp2_oracle_read(self.handle, _ptr(c), _ptr(l)))
+        return c, l
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.lcp2_oracle_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One prover context = one GPU + one HIP stream (lcp2_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.lcp2_ctx_create(device, stream, ctypes.byref(h))
+        if rc:
+            raise Lcp2Error(rc, self.lib.lcp2_status_str(rc).decode())
+        self.handle = h
+
+    def _check(self, rc):
+        if rc:
+            msg = self.lib.lcp2_status_str(rc).decode()
+            detail = self.lib.lcp2_last_error(self.handle)
+            raise Lcp2Error(rc, msg + (": " + detail.decode() if detail else ""))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lcp2_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.lcp2_ctx_sync(self.handle))
+
+    # ---- primitives on host numpy arrays
+    def poseidon_permute_batch(self, states):
+        s = _np_u64(states).reshape(-1, 12)
+        out = np.empty_like(s)
+        self._check(self.lib.lcp2_poseidon_permute_batch(self.handle, _ptr(s), _ptr(out), s.shape[0], MEM_HOST))
+        return out
+
+    def merkle_cap(self, leaves, cap_height):
+        l = _np_u64(leaves)
+        assert l.ndim == 2
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        self._check(self.lib.lcp2_merkle_cap(self.handle, _ptr(l), l.shape[0], l.shape[1], cap_height, MEM_HOST, _ptr(cap)))
+        return cap
+
+    def ntt_batch(self, cols, inverse=False, shift=1):
+        c = _np_u64(cols).copy()
+        assert c.ndim == 2
+        log_n = int(c.shape[1]).bit_length() - 1
+        assert 1 << log_n == c.shape[1]
+        self._check(self.lib.lcp2_ntt_batch(self.handle, _ptr(c), c.shape[0], log_n, int(inverse), shift, MEM_HOST))
+        return c
+
+    def lde_batch(self, coeffs, rate_bits=3):
+        c = _np_u64(coeffs)
+        log_n = int(c.shape[1]).bit_length() - 1
+        out = np.zeros((c.shape[0], c.shape[1] << rate_bits), dtype=np.uint64)
+        self._check(self.lib.lcp2_lde_batch(self.handle, _ptr(c), _ptr(out), c.shape[0], log_n, rate_bits, MEM_HOST))
+        return out
+
+    def sha256_tree(self, leaves, height, trees=1, trace=False):
+        l = np.ascontiguousarray(leaves, dtype=np.uint8).reshape(trees, 1 << height, 32)
+        nodes = np.zeros((trees, (2 << height) - 1, 32), dtype=np.uint8)
+        tr = np.zeros((trees, (1 << height) - 1, 2, 176), dtype=np.uint32) if trace else None
+        self._check(self.lib.lcp2_sha256_tree(self.handle, _ptr(l), height, trees, _ptr(nodes), _ptr(tr), MEM_HOST))
+        return (nodes, tr) if trace else nodes
+
+    def _commit(self, fn, cols, rate_bits, cap_height, mem, shape):
+        if mem == MEM_HOST:
+            c = _np_u64(cols)
+            ncols, n = c.shape
+            p = _ptr(c)
+        else:
+            ncols, n = shape
+            p = ctypes.c_void_p(cols)
+        log_n = int(n).bit_length() - 1
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        h = ctypes.c_void_p()
+        self._check(fn(self.handle, p, ncols, log_n, rate_bits, cap_height, mem, ctypes.byref(h), _ptr(cap)))
+        return Oracle(self, h, ncols, log_n, rate_bits, cap_height, cap)
+
+    def commit_values(self, cols, rate_bits=3, cap_height=4, mem=MEM_HOST, shape=None):
+        """PolynomialBatch::from_values.  cols: numpy [ncols][n] or a device pointer with shape=(ncols, n)."""
+        return self._commit(self.lib.lcp2_commit_values, cols, rate_bits, cap_height, mem, shape)
+
+    def commit_coeffs(self, cols, rate_bits=3, cap_height=4, mem=MEM_HOST, shape=None):
+        return self._commit(self.lib.lcp2_commit_coeffs, cols, rate_bits, cap_height, mem, shape)
+
+    # ---- timing
+    def prof_enable(self, on=True):
+        self._check(self.lib.lcp2_prof_enable(self.handle, int(on)))
+
+    def prof_reset(self):
+        self._check(self.lib.lcp2_prof_reset(self.handle))
+
+    def prof_get(self):
+        out = {}
+        for i, name in enumerate(KERNEL_FAMILIES):
+            ms, n, b = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
+            self._check(self.lib.lcp2_prof_get(self.handle, i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
+            out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
+        return out

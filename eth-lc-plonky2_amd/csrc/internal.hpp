@@ -1,0 +1,136 @@
+// Internal declarations shared by the .hip translation units of liblcp2.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/lcp2.h"
+#include "gl64.hpp"
+#include "ntt.hpp"
+
+namespace lcp2 {
+
+struct ProfFamily {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0;
+  uint64_t launches = 0;
+  double bytes = 0;
+};
+
+}  // namespace lcp2
+
+struct lcp2_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  lcp2::u64 *d_rc = nullptr;  // 360 Poseidon round constants
+  std::map<std::string, lcp2::u64 *> tables;
+  bool prof_on = false;
+  lcp2::ProfFamily fam[LCP2_K_COUNT];
+  std::vector<hipEvent_t> event_pool;
+
+  int fail(int code, const std::string &msg) {
+    last_error = msg;
+    return code;
+  }
+};
+
+namespace lcp2 {
+
+#define LCP2_HIP(ctx, expr)                                                                  \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return (ctx)->fail(e_ == hipErrorOutOfMemory ? LCP2_E_OOM : LCP2_E_HIP,                \
+                         std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+// RAII device allocation
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) n = 8;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n; else p = nullptr;
+    return e;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  u64 *u() const { return (u64 *)p; }
+};
+
+// scope-based event timing of one kernel family (no-op unless profiling is enabled)
+struct ProfScope {
+  lcp2_ctx *ctx;
+  int family;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(lcp2_ctx *c, int fam, double algorithmic_bytes);
+  ~ProfScope();
+};
+
+// ---- kernel launch wrappers (device pointers, asynchronous on `s`) ----
+void launch_poseidon_permute_batch(hipStream_t s, const u64 *in, u64 *out, size_t count, const u64 *rc);
+// leaf i, element c at  data[i * leaf_stride + c * col_stride]
+void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col_stride, u32 leaf_len, u64 nleaves,
+                        u64 *digests, const u64 *rc);
+// leaves of `arity` extension elements taken from two planes (c0, c1): leaf k = flatten(e[arity*k .. arity*(k+1)))
+void launch_hash_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, u64 nleaves, u64 *digests, const u64 *rc);
+void launch_merkle_level(hipStream_t s, const u64 *children, u64 *parents, u64 nparents, const u64 *rc);
+void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz);
+void launch_bitrev_tile(hipStream_t s, const BitrevTile &b, u32 wgs, u32 cols);
+void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols);
+void launch_sha256_level(hipStream_t s, const uint8_t *children, uint8_t *parents, u64 nparents_per_tree, u64 trees,
+                         u64 child_tree_stride, u64 parent_tree_stride, uint32_t *trace, u64 trace_tree_stride,
+                         u64 trace_hash_offset);
+void launch_gather_rows(hipStream_t s, const u64 *data, u64 col_stride, u32 ncols, const u64 *indices, u32 k, u64 *out);
+void launch_gather_digests(hipStream_t s, const u64 *digests, const u64 *level_offsets, u32 nsib, const u64 *indices,
+                           u32 k, u64 *out);
+
+// ---- device-side NTT backend over the launch wrappers ----
+struct DeviceNttBackend {
+  lcp2_ctx *ctx;
+  int status = 0;
+  const u64 *table(const std::string &key, std::function<std::vector<u64>()> make);
+  void launch_pass(bool inv, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) { launch_ntt_pass(ctx->stream, inv, p, wgs, cols, nz); }
+  void launch_bitrev(const BitrevTile &b, u32 wgs, u32 cols) { launch_bitrev_tile(ctx->stream, b, wgs, cols); }
+  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
+    lcp2::launch_bitrev_small(ctx->stream, in, is, out, os, lg, cols);
+  }
+};
+
+}  // namespace lcp2
+
+// = PolynomialBatch
+struct lcp2_oracle {
+  lcp2_ctx *ctx = nullptr;
+  uint32_t ncols = 0, log_n = 0, rate_bits = 0, cap_height = 0;
+  lcp2::DevBuf coeffs;   // [ncols][n], natural coefficient order
+  lcp2::DevBuf lde;      // [ncols][n << rate_bits], Merkle leaf order
+  lcp2::DevBuf digests;  // level 0 (leaf digests) ... cap level, 4 u64 per node
+  std::vector<uint64_t> level_off;  // node offset of each level inside `digests`
+  lcp2::DevBuf d_level_off;
+  uint64_t nleaves() const { return (uint64_t)1 << (log_n + rate_bits); }
+  uint32_t nlevels() const { return log_n + rate_bits - cap_height + 1; }
+  const lcp2::u64 *cap_dev() const { return digests.u() + 4 * level_off.back(); }
+};
+
+namespace lcp2 {
+// internal commitment builders on device-resident input
+int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                      uint32_t cap_height, lcp2_oracle *o);
+int commit_coeffs_dev(lcp2_ctx *ctx, const u64 *d_coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                      uint32_t cap_height, lcp2_oracle *o, bool take_copy);
+int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o);
+}  // namespace lcp2

@@ -1,0 +1,59 @@
+// NTT pass kernels for gfx950 (rows a2, a3, a4 of SURVEY.md section 8): see ntt.hpp for the
+// decomposition.  One workgroup = one 2^L-element slab in LDS (up to 64 KiB, so two
+// workgroups share a CU's 160 KiB), 256 threads, one barrier per radix-2 stage.
+// Global traffic is one read and one write of the slab per pass, in runs of >= 128 bytes.
+#include "internal.hpp"
+
+namespace lcp2 {
+
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  NttPass pass{p};
+  const u32 tid = threadIdx.x, wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z;
+  pass.template load<INV>(lds, tid, NTT_THREADS, wg, col, z);
+  __syncthreads();
+  if (!INV) {
+    for (int b = (int)(p.S + p.B) - 1; b >= (int)p.S; b--) {
+      pass.template stage<false>(lds, tid, NTT_THREADS, (u32)b);
+      __syncthreads();
+    }
+  } else {
+    for (u32 b = p.S; b < p.S + p.B; b++) {
+      pass.template stage<true>(lds, tid, NTT_THREADS, b);
+      __syncthreads();
+    }
+  }
+  pass.template store<INV>(lds, tid, NTT_THREADS, wg, col, z);
+}
+
+__global__ __launch_bounds__(256) void k_bitrev_tile(BitrevTile b) {
+  __shared__ u64 lds[64 * 65];
+  b.load(lds, threadIdx.x, 256, blockIdx.x, blockIdx.y);
+  __syncthreads();
+  b.store(lds, threadIdx.x, 256, blockIdx.x, blockIdx.y);
+}
+
+__global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restrict__ out, u64 os, u32 lg) {
+  u32 col = blockIdx.y;
+  u32 n = 1u << lg;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[(u64)col * os + bitrev32(i, lg)] = gl_canon(in[(u64)col * is + i]);
+}
+
+void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
+  size_t lds_bytes = (size_t)8 << p.L;
+  dim3 grid(wgs, cols, nz);
+  if (inverse) hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds_bytes, s, p);
+  else hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds_bytes, s, p);
+}
+void launch_bitrev_tile(hipStream_t s, const BitrevTile &b, u32 wgs, u32 cols) {
+  hipLaunchKernelGGL(k_bitrev_tile, dim3(wgs, cols), dim3(256), 0, s, b);
+}
+void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
+  u32 n = 1u << lg;
+  u32 blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_bitrev_small, dim3(blocks, cols), dim3(256), 0, s, in, is, out, os, lg);
+}
+
+}  // namespace lcp2

@@ -1,0 +1,166 @@
+/*
+ * lcp2.h -- C ABI of the MI355X (gfx950) Plonky2 prover backend for the
+ * Ethereum light-client circuit of Electron-Labs/eth-lc-plonky2.
+ *
+ * What this replaces.  The reference (Rust) reaches its prover through exactly
+ *     builder.build::<C>() -> data.prove(pw) -> data.verify(proof)
+ * (eth-lc-plonky2/src/main.rs:226-233, src/unit_tests.rs:29-35) with
+ * F = GoldilocksField, C = PoseidonGoldilocksConfig, D = 2 and
+ * CircuitConfig::standard_recursion_config() (src/main.rs:74-79).  Everything
+ * below that call lives in the un-vendored crates plonky2 0.1.4 / plonky2_field
+ * 0.1.1 (@666f3151, Cargo.lock:2347-2350,2425-2427) and plonky2_crypto
+ * (@3f713785, Cargo.lock:2388-2390).  Each entry point names the plonky2
+ * function a Rust fork would forward to it (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - return 0 (LCP2_OK) or a negative lcp2_status; nothing throws or aborts
+ *    across the ABI.  An unsatisfiable witness gives LCP2_E_UNSAT, mirroring
+ *    the `Err` of `prove()` that the reference's #[should_panic] tests rely on.
+ *  - field elements are little-endian uint64_t Goldilocks values; inputs may be
+ *    non-canonical (any value < 2^64), outputs are canonical.
+ *  - extension elements are two uint64_t [c0, c1] (X^2 = 7).
+ *  - every buffer argument is followed by an lcp2_mem saying where it lives.
+ *    Device buffers must belong to the context's device.  Calls are
+ *    asynchronous on the context's stream only for LCP2_MEM_DEVICE outputs;
+ *    host outputs are complete on return.
+ *  - a context is bound to one device and is NOT thread-safe; distinct
+ *    contexts may be used concurrently.  No global mutable state.
+ *  - there is no CPU fallback: without a usable HIP device every call that
+ *    needs one returns LCP2_E_NODEVICE.
+ */
+#ifndef LCP2_H
+#define LCP2_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCP2_ABI_VERSION 1
+
+typedef enum {
+  LCP2_OK = 0,
+  LCP2_E_INVALID = -1,     /* bad argument / shape */
+  LCP2_E_NODEVICE = -2,    /* no usable HIP device */
+  LCP2_E_HIP = -3,         /* HIP runtime error (see lcp2_last_error) */
+  LCP2_E_OOM = -4,
+  LCP2_E_UNSAT = -5,       /* witness does not satisfy the circuit */
+  LCP2_E_UNSUPPORTED = -6,
+  LCP2_E_VERIFY = -7       /* proof rejected */
+} lcp2_status;
+
+typedef enum { LCP2_MEM_HOST = 0, LCP2_MEM_DEVICE = 1 } lcp2_mem;
+
+/* CircuitConfig + FriConfig (plonky2 `CircuitConfig::standard_recursion_config()`,
+ * reference call site src/main.rs:78) plus the per-circuit degree. */
+#define LCP2_MAX_FRI_LAYERS 8
+typedef struct {
+  uint32_t degree_bits;            /* n = 2^degree_bits rows */
+  uint32_t num_wires;              /* 135 */
+  uint32_t num_routed_wires;       /* 80  */
+  uint32_t num_constants;          /* constant columns incl. selectors */
+  uint32_t rate_bits;              /* 3 */
+  uint32_t cap_height;             /* 4 */
+  uint32_t num_challenges;         /* 2 */
+  uint32_t quotient_degree_factor; /* 8 */
+  uint32_t proof_of_work_bits;     /* 16 */
+  uint32_t num_query_rounds;       /* 28 */
+  uint32_t num_fri_layers;         /* derived by lcp2_params_standard */
+  uint32_t fri_arity_bits[LCP2_MAX_FRI_LAYERS];
+} lcp2_params;
+
+/* Fills `p` with standard_recursion_config() for a circuit of 2^degree_bits rows,
+ * including the ConstantArityBits(4, 5) reduction schedule. */
+int lcp2_params_standard(uint32_t degree_bits, uint32_t num_constants, lcp2_params *p);
+
+typedef struct lcp2_ctx lcp2_ctx;
+typedef struct lcp2_oracle lcp2_oracle; /* = plonky2 PolynomialBatch, device resident */
+
+const char *lcp2_status_str(int status);
+int lcp2_abi_version(void);
+int lcp2_device_count(void);
+
+/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. the caller's
+ * current stream) or NULL for a private stream. */
+int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out);
+void lcp2_ctx_destroy(lcp2_ctx *ctx);
+int lcp2_ctx_sync(lcp2_ctx *ctx);
+const char *lcp2_last_error(lcp2_ctx *ctx);
+
+/* ------------------------------------------------------------------ primitives
+ * (tests / micro-benchmarks; the same kernels the prover uses) */
+
+/* PoseidonPermutation::permute on `count` independent width-12 states
+ * (plonky2 hash/poseidon.rs).  in/out: [count][12]. */
+int lcp2_poseidon_permute_batch(lcp2_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, lcp2_mem mem);
+
+/* MerkleTree::new(leaves, cap_height) (plonky2 hash/merkle_tree.rs): leaves is
+ * row-major [nleaves][leaf_len]; cap receives 2^cap_height digests of 4 elements. */
+int lcp2_merkle_cap(lcp2_ctx *ctx, const uint64_t *leaves, size_t nleaves, size_t leaf_len,
+                    uint32_t cap_height, lcp2_mem mem, uint64_t *cap /* host */);
+
+/* plonky2_field fft / ifft / coset_fft / coset_ifft on `ncols` polynomials of
+ * 2^log_n elements, column-major [ncols][2^log_n], natural order in and out,
+ * in place.  inverse = 0: values_i = sum_j c_j (shift w^i)^j ; inverse = 1 undoes it.
+ * shift = 1 for the plain transforms. */
+int lcp2_ntt_batch(lcp2_ctx *ctx, uint64_t *data, size_t ncols, uint32_t log_n, int inverse,
+                   uint64_t shift, lcp2_mem mem);
+
+/* PolynomialCoeffs::lde(rate_bits) + coset_fft(7) for every column, emitted in
+ * Merkle LEAF ORDER (plonky2 applies `reverse_index_bits_in_place` before
+ * hashing): out[col][i] = f_col(7 * w_{n<<r}^bitrev(i)), out is [ncols][n << rate_bits]. */
+int lcp2_lde_batch(lcp2_ctx *ctx, const uint64_t *coeffs, uint64_t *out, size_t ncols, uint32_t log_n,
+                   uint32_t rate_bits, lcp2_mem mem);
+
+/* Native SHA-256 Merkle tree of the reference's `add_virtual_merkle_tree_sha256_target`
+ * (src/merkle_tree_gadget.rs:42-59): leaves [2^height][32] bytes; nodes receives every
+ * level, leaves first then 2^(height-1) ... 1 digests ((2^(height+1)-1)*32 bytes).
+ * `trees` independent trees are processed in one launch chain (leaves and nodes
+ * are arrays of that many trees).  round_trace (nullable) receives, per
+ * two_to_one hash and per compression (2 per hash), 48 schedule words followed
+ * by 64 (a, e) register pairs: the values the in-circuit witness needs. */
+int lcp2_sha256_tree(lcp2_ctx *ctx, const uint8_t *leaves, uint32_t height, size_t trees,
+                     uint8_t *nodes, uint32_t *round_trace, lcp2_mem mem);
+
+/* ------------------------------------------------------------------ polynomial commitments
+ * PolynomialBatch::from_values / from_coeffs (plonky2 fri/oracle.rs): ifft,
+ * lde x 2^rate_bits on the coset 7H, leaf hashing, Merkle tree with cap.
+ * cols: column-major [ncols][2^log_n].  The oracle keeps coefficients, LDE and
+ * all digests in HBM.  cap: host, 2^cap_height * 4 elements (nullable). */
+int lcp2_commit_values(lcp2_ctx *ctx, const uint64_t *cols, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                       uint32_t cap_height, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap);
+int lcp2_commit_coeffs(lcp2_ctx *ctx, const uint64_t *coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                       uint32_t cap_height, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap);
+void lcp2_oracle_destroy(lcp2_oracle *o);
+/* MerkleTree::prove + leaf lookup for `k` leaf indices (fri_prover_query_round):
+ * leaves [k][ncols], siblings [k][log2(nleaves) - cap_height][4]; host buffers. */
+int lcp2_oracle_open(lcp2_oracle *o, const uint64_t *indices, size_t k, uint64_t *leaves, uint64_t *siblings);
+/* copies for tests: coefficients [ncols][n] and LDE [ncols][n << rate_bits] (leaf order), host buffers */
+int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs /* nullable */, uint64_t *lde /* nullable */);
+
+/* ------------------------------------------------------------------ timing
+ * Per-kernel-family HIP-event timing on the context's stream.  Accumulates
+ * while enabled; lcp2_prof_get synchronises and reports totals since the last reset. */
+typedef enum {
+  LCP2_K_INTT = 0,      /* K1 */
+  LCP2_K_LDE = 1,       /* K2 */
+  LCP2_K_LEAF_HASH = 2, /* K4a */
+  LCP2_K_MERKLE = 3,    /* K4b */
+  LCP2_K_PERM_Z = 4,    /* K5 */
+  LCP2_K_QUOTIENT = 5,  /* K6 */
+  LCP2_K_OPENINGS = 6,  /* K7 */
+  LCP2_K_FRI = 7,       /* K8 */
+  LCP2_K_POW = 8,       /* K9 */
+  LCP2_K_SHA256 = 9,    /* K10 */
+  LCP2_K_OTHER = 10,
+  LCP2_K_COUNT = 11
+} lcp2_kernel_family;
+int lcp2_prof_enable(lcp2_ctx *ctx, int on);
+int lcp2_prof_reset(lcp2_ctx *ctx);
+int lcp2_prof_get(lcp2_ctx *ctx, int family, double *total_ms, uint64_t *launches, double *algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

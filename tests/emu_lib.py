@@ -1,0 +1,25 @@
+"""Builds/loads tests/emu/libemu.so: CPU emulation of the device kernels' phases (test harness only)."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "emu.cpp")
+LIB = os.path.join(HERE, "emu", "libemu.so")
+CSRC = os.path.join(HERE, "..", "eth-lc-plonky2_amd", "csrc")
+
+
+def load():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC], check=True)
+    E = ctypes.CDLL(LIB)
+    c = ctypes
+    V = c.c_void_p
+    E.emu_poseidon_permute.argtypes = [V]
+    E.emu_gl_mul.restype = c.c_uint64
+    E.emu_gl_mul.argtypes = [c.c_uint64, c.c_uint64]
+    E.emu_ntt_forward.argtypes = [V, V, c.c_uint32, c.c_uint32, c.c_uint64, c.c_uint32]
+    E.emu_ntt_inverse_natural.argtypes = [V, V, c.c_uint32, c.c_uint32]
+    E.emu_ntt_inverse_bitrev.argtypes = [V, V, c.c_uint32, c.c_uint32, c.c_uint64]
+    return E

@@ -1,0 +1,210 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every primitive goes through the C ABI
+(include/lcp2.h) and is compared bit for bit with the oracle on the same seeded inputs."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import P, bitrev_perm, commit_reference, lde_leaf_order, merkle_cap, merkle_verify, rand_field, vp
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_poseidon_batch_parity(gpu_ctx, oracle):
+    rng = np.random.default_rng(10)
+    n = 5000  # not a multiple of the block size
+    s = rand_field(rng, (n, 12), canonical=False)
+    s[0] = 0
+    s[1] = np.arange(12)
+    s[2] = P - 1
+    got = gpu_ctx.poseidon_permute_batch(s)
+    want = np.zeros_like(s)
+    oracle.orc_poseidon_permute_batch(vp(s), vp(want), n)
+    assert (got == want).all()
+    pos = json.load(open(os.path.join(G, "poseidon_kat.json")))
+    for i, v in enumerate(pos["vectors"]):
+        assert ["%016x" % x for x in got[i]] == v["out"]
+    assert gpu_ctx.poseidon_permute_batch(np.zeros((0, 12), dtype=np.uint64)).shape == (0, 12)
+
+
+@pytest.mark.parametrize("leaf_len", [1, 3, 4, 5, 8, 9, 16, 20, 32, 135])
+@pytest.mark.parametrize("log_leaves,cap_height", [(4, 4), (5, 4), (6, 0), (9, 4), (11, 2)])
+def test_merkle_cap_parity(gpu_ctx, oracle, leaf_len, log_leaves, cap_height):
+    rng = np.random.default_rng(leaf_len * 100 + log_leaves)
+    leaves = rand_field(rng, (1 << log_leaves, leaf_len), canonical=False)
+    got = gpu_ctx.merkle_cap(leaves, cap_height)
+    want = merkle_cap(oracle, leaves, cap_height)
+    assert (got == want).all()
+
+
+def test_merkle_cap_rejects_bad_shapes(gpu_ctx):
+    import eth_lc_plonky2_amd as m
+    with pytest.raises(m.Lcp2Error):
+        gpu_ctx.merkle_cap(np.zeros((8, 5), dtype=np.uint64), 4)  # cap higher than the tree
+    with pytest.raises(m.Lcp2Error):
+        gpu_ctx.merkle_cap(np.zeros((6, 5), dtype=np.uint64), 1)  # not a power of two
+
+
+@pytest.mark.parametrize("lg", [1, 2, 3, 6, 10, 11, 12, 13, 14, 16, 18])
+def test_ntt_parity(gpu_ctx, oracle, lg):
+    rng = np.random.default_rng(lg)
+    n, ncols = 1 << lg, 3
+    x = rand_field(rng, (ncols, n), canonical=False)
+    xc = x % np.uint64(P)
+    want = xc.copy()
+    oracle.orc_fft_batch(vp(want), ncols, n)
+    assert (gpu_ctx.ntt_batch(x) == want).all()
+    assert (gpu_ctx.ntt_batch(want, inverse=True) == xc).all()
+    co = xc.copy()
+    for c in range(ncols):
+        oracle.orc_coset_fft(vp(co[c]), n, 7)
+    assert (gpu_ctx.ntt_batch(x, shift=7) == co).all()
+    assert (gpu_ctx.ntt_batch(co, inverse=True, shift=7) == xc).all()
+
+
+@pytest.mark.parametrize("lg,ncols", [(1, 2), (4, 5), (10, 3), (13, 2), (14, 2), (16, 1)])
+def test_lde_parity(gpu_ctx, oracle, lg, ncols):
+    rng = np.random.default_rng(lg + 50)
+    c = rand_field(rng, (ncols, 1 << lg), canonical=False)
+    got = gpu_ctx.lde_batch(c, 3)
+    assert (got == lde_leaf_order(oracle, c % np.uint64(P), 3)).all()
+
+
+def test_ntt_large_roundtrip_and_linearity(gpu_ctx):
+    # full-size property test (n = 2^22, the BASELINE degree): inverse(forward(x)) = x, and NTT(a+b) = NTT(a)+NTT(b)
+    rng = np.random.default_rng(22)
+    n = 1 << 22
+    a = rand_field(rng, (1, n))
+    b = rand_field(rng, (1, n))
+    fa = gpu_ctx.ntt_batch(a, shift=7)
+    assert (gpu_ctx.ntt_batch(fa, inverse=True, shift=7) == a).all()
+    fb = gpu_ctx.ntt_batch(b, shift=7)
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    fs = gpu_ctx.ntt_batch(s, shift=7)
+    assert (fs == ((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64)).all()
+    # spot-check the definition on a sparse polynomial: c_5 = 1  ->  v_i = (7 w^i)^5
+    sp = np.zeros((1, n), dtype=np.uint64)
+    sp[0, 5] = 1
+    v = gpu_ctx.ntt_batch(sp, shift=7)
+    w = pow(pow(7, (P - 1) >> 32, P), 1 << (32 - 22), P)
+    for i in (0, 1, 12345, n - 1):
+        assert int(v[0, i]) == pow(7 * pow(w, i, P), 5, P)
+
+
+def test_sha256_tree_golden_roots(gpu_ctx, oracle):
+    kat = json.load(open(os.path.join(G, "sha256_kat.json")))
+    for n, root in kat["zero_leaf_merkle_roots"].items():
+        h = int(n).bit_length() - 1
+        nodes = gpu_ctx.sha256_tree(np.zeros((int(n), 32), dtype=np.uint8), h)
+        assert bytes(nodes[0, -1]).hex() == root
+    # SyncCommitteeSSZ (config 2): 1024-leaf tree + the two 2-leaf trees, root pinned by the reference's test
+    sc = kat["sync_committee"]
+    pks = np.frombuffer(bytes.fromhex("".join(sc["pubkeys"])), dtype=np.uint8).copy()
+    leaves = np.zeros((1024, 32), dtype=np.uint8)
+    oracle.orc_ssz_sync_committee_leaves(vp(pks), vp(leaves))
+    nodes, trace = gpu_ctx.sha256_tree(leaves, 10, trace=True)
+    pk_root = nodes[0, -1]
+    agg = np.zeros(64, dtype=np.uint8)
+    agg[:48] = np.frombuffer(bytes.fromhex(sc["aggregate_pubkey"]), dtype=np.uint8)
+    agg_root = gpu_ctx.sha256_tree(agg.reshape(2, 32), 1)[0, -1]
+    top = gpu_ctx.sha256_tree(np.stack([pk_root, agg_root]), 1)[0, -1]
+    assert bytes(top).hex() == sc["ssz_root"]
+    # every node equals the oracle's, every round-trace word equals the oracle's compression trace
+    want_nodes = np.zeros((2047, 32), dtype=np.uint8)
+    root = np.zeros(32, dtype=np.uint8)
+    oracle.orc_sha256_merkle_root(vp(leaves), 10, vp(root), vp(want_nodes))
+    assert (nodes[0] == want_nodes).all()
+    H0 = np.array([0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19], dtype=np.uint32)
+    for hid in (0, 1, 511, 512, 1000, 1022):
+        child = 2 * hid  # node index of the left child in level-major order
+        blk = np.frombuffer(bytes(want_nodes[child]) + bytes(want_nodes[child + 1]), dtype=">u4").astype(np.uint32)
+        st = H0.copy()
+        tr = np.zeros(176, dtype=np.uint32)
+        oracle.orc_sha256_compress(vp(st), vp(blk), vp(tr))
+        assert (trace[0, hid, 0] == tr).all()
+        pad = np.zeros(16, dtype=np.uint32)
+        pad[0], pad[15] = 0x80000000, 512
+        oracle.orc_sha256_compress(vp(st), vp(pad), vp(tr))
+        assert (trace[0, hid, 1] == tr).all()
+
+
+def test_sha256_many_trees(gpu_ctx):
+    rng = np.random.default_rng(7)
+    trees, h = 5, 3
+    leaves = rng.integers(0, 256, size=(trees, 1 << h, 32), dtype=np.uint8)
+    nodes = gpu_ctx.sha256_tree(leaves, h, trees=trees)
+    for t in range(trees):
+        lvl = [bytes(x) for x in leaves[t]]
+        while len(lvl) > 1:
+            lvl = [hashlib.sha256(lvl[2 * i] + lvl[2 * i + 1]).digest() for i in range(len(lvl) // 2)]
+        assert bytes(nodes[t, -1]) == lvl[0]
+
+
+@pytest.mark.parametrize("lg,ncols", [(1, 3), (3, 4), (5, 135), (9, 20), (12, 16), (13, 7), (14, 3)])
+def test_commit_values_parity(gpu_ctx, oracle, lg, ncols):
+    rng = np.random.default_rng(lg * 1000 + ncols)
+    vals = rand_field(rng, (ncols, 1 << lg), canonical=False)
+    cap_h = min(4, lg + 3)
+    o = gpu_ctx.commit_values(vals, 3, cap_h)
+    coeffs, lde, cap = commit_reference(oracle, vals, 3, cap_h)
+    assert (o.cap == cap).all()
+    gc, gl = o.read()
+    assert (gc == coeffs).all() and (gl == lde).all()
+    idx = np.array([0, 1, (8 << lg) - 1, (8 << lg) // 3], dtype=np.uint64)
+    leaves, sib = o.open(idx)
+    for q, i in enumerate(idx):
+        assert (leaves[q] == lde[:, int(i)]).all()
+        assert merkle_verify(oracle, leaves[q], i, sib[q], cap)
+        bad = leaves[q].copy()
+        bad[0] ^= np.uint64(1)
+        assert not merkle_verify(oracle, bad, i, sib[q], cap)
+    o2 = gpu_ctx.commit_coeffs(coeffs, 3, cap_h)
+    assert (o2.cap == cap).all()
+    o.close()
+    o2.close()
+
+
+def test_commit_small_values_trace(gpu_ctx, oracle):
+    # SHA-256 traces are byte- and u32-valued: mixed small columns catch canonicalisation shortcuts
+    rng = np.random.default_rng(99)
+    lg, ncols = 10, 24
+    vals = np.zeros((ncols, 1 << lg), dtype=np.uint64)
+    vals[0::2] = rng.integers(0, 256, size=(ncols // 2, 1 << lg), dtype=np.uint64)
+    vals[1::2] = rng.integers(0, 2 ** 32, size=(ncols // 2, 1 << lg), dtype=np.uint64)
+    o = gpu_ctx.commit_values(vals)
+    assert (o.cap == commit_reference(oracle, vals)[2]).all()
+
+
+def test_commit_large_properties(gpu_ctx, oracle):
+    # n = 2^20, 16 columns: Merkle openings verify against the cap with the oracle's verifier and the LDE rows
+    # equal the committed polynomials evaluated at 7 * w^bitrev(i)
+    rng = np.random.default_rng(20)
+    lg, ncols = 20, 16
+    n = 1 << lg
+    vals = rand_field(rng, (ncols, n))
+    o = gpu_ctx.commit_values(vals)
+    coeffs, _ = o.read(lde=False)
+    # coefficients interpolate the values: evaluate two columns at w^k by Horner for a few k
+    w = pow(pow(7, (P - 1) >> 32, P), 1 << (32 - lg), P)
+    for c in (0, ncols - 1):
+        cc = [int(x) for x in coeffs[c]]
+        for k in (0, 1, 77777):
+            x, acc = pow(w, k, P), 0
+            for a in reversed(cc):
+                acc = (acc * x + a) % P
+            assert acc == int(vals[c, k])
+    idx = rng.integers(0, 8 * n, size=6, dtype=np.uint64)
+    leaves, sib = o.open(idx)
+    W = pow(pow(7, (P - 1) >> 32, P), 1 << (32 - lg - 3), P)
+    perm_bits = lg + 3
+    for q, i in enumerate(idx):
+        assert merkle_verify(oracle, leaves[q], i, sib[q], o.cap)
+        r = int(format(int(i), "0%db" % perm_bits)[::-1], 2)
+        x, acc = 7 * pow(W, r, P) % P, 0
+        for a in reversed([int(v) for v in coeffs[3]]):
+            acc = (acc * x + a) % P
+        assert acc == int(leaves[q, 3])
+    o.close()
