@@ -5,6 +5,7 @@ eth-lc-plonky2/src/main.rs:226-233) over the C ABI in include/lcp2.h.  The
 directory name follows the project ("eth-lc-plonky2_amd"); import it as
 `eth_lc_plonky2_amd` (shim module at the repository root).
 """
-from .binding import (Context, Lcp2Error, Oracle, Params, load_library, standard_params,  # noqa: F401
+from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Params, load_library, standard_params,  # noqa: F401
                       MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P)
 from .build import build_native  # noqa: F401
+from . import circuit  # noqa: F401,E402

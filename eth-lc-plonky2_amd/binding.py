@@ -36,6 +36,14 @@ class Params(ctypes.Structure):
     _fields_.append(("fri_arity_bits", ctypes.c_uint32 * 8))
 
 
+class CircuitDesc(ctypes.Structure):
+    _fields_ = [("params", Params), ("constants_sigmas", ctypes.c_void_p), ("constants_sigmas_mem", ctypes.c_int),
+                ("k_is", ctypes.c_void_p), ("num_selectors", ctypes.c_uint32), ("num_gates", ctypes.c_uint32),
+                ("gates", ctypes.c_void_p), ("code", ctypes.c_void_p), ("code_words", ctypes.c_size_t),
+                ("imm", ctypes.c_void_p), ("num_imm", ctypes.c_size_t), ("num_public_inputs", ctypes.c_uint32),
+                ("num_regs", ctypes.c_uint32)]
+
+
 _lib = None
 
 
@@ -68,6 +76,14 @@ def load_library():
         "lcp2_oracle_destroy": (None, [c.c_void_p]),
         "lcp2_oracle_open": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]),
         "lcp2_oracle_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_circuit_create": (c.c_int, [c.c_void_p, c.POINTER(CircuitDesc), c.POINTER(c.c_void_p)]),
+        "lcp2_verifier_create": (c.c_int, [c.POINTER(CircuitDesc), c.c_void_p, c.c_void_p, c.POINTER(c.c_void_p)]),
+        "lcp2_circuit_destroy": (None, [c.c_void_p]),
+        "lcp2_circuit_digest": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_proof_words": (c.c_size_t, [c.POINTER(Params)]),
+        "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p]),
+        "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(c.c_int)]),
+        "lcp2_last_challenges": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
         "lcp2_prof_reset": (c.c_int, [c.c_void_p]),
         "lcp2_prof_get": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_uint64), c.POINTER(c.c_double)]),
@@ -239,3 +255,106 @@ class Context:
             self._check(self.lib.lcp2_prof_get(self.handle, i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
             out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
         return out
+
+
+class ProofRejected(Lcp2Error):
+    """data.verify(proof) failed; .check names the failed step (see lcp2_verify)."""
+
+    def __init__(self, check):
+        super().__init__(-7, f"proof rejected (check {check})")
+        self.check = check
+
+
+def _describe(circ, constants_sigmas_ptr=None, mem=MEM_HOST):
+    """lcp2_circuit_desc for a circuit.Circuit; returns (desc, keepalive)"""
+    gs = circ.gateset
+    gates = circ.gates_array
+    d = CircuitDesc()
+    d.params = circ.params
+    d.constants_sigmas = constants_sigmas_ptr if constants_sigmas_ptr is not None else circ.constants_sigmas.ctypes.data
+    d.constants_sigmas_mem = mem
+    d.k_is = circ.k_is.ctypes.data
+    d.num_selectors, d.num_gates = gs.num_selectors, len(gs.gates)
+    d.gates = ctypes.cast(gates, ctypes.c_void_p)
+    d.code, d.code_words = gs.code.ctypes.data, gs.code_len
+    d.imm, d.num_imm = gs.imm.ctypes.data, gs.imm.size
+    d.num_public_inputs, d.num_regs = circ.num_public_inputs, gs.max_regs
+    return d, (gates, gs, circ)
+
+
+class CircuitData:
+    """builder.build::<C>() result: the handle `prove` and `verify` are called on
+    (reference: eth-lc-plonky2/src/main.rs:227-233)."""
+
+    def __init__(self, ctx, circ, handle, keep):
+        self.ctx, self.circ, self.handle, self._keep = ctx, circ, handle, keep
+        self.lib = load_library()
+        self.proof_words = self.lib.lcp2_proof_words(ctypes.byref(circ.params))
+
+    @classmethod
+    def build(cls, ctx, circ, constants_sigmas_ptr=None, mem=MEM_HOST):
+        d, keep = _describe(circ, constants_sigmas_ptr, mem)
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.lcp2_circuit_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
+        return cls(ctx, circ, h, keep)
+
+    @classmethod
+    def verifier_only(cls, circ, digest, cap):
+        lib = load_library()
+        d, keep = _describe(circ, 0)
+        h = ctypes.c_void_p()
+        dg, cp = _np_u64(digest), _np_u64(cap)
+        rc = lib.lcp2_verifier_create(ctypes.byref(d), _ptr(dg), _ptr(cp), ctypes.byref(h))
+        if rc:
+            raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+        return cls(None, circ, h, keep)
+
+    def _check(self, rc):
+        if rc:
+            if self.ctx is not None:
+                self.ctx._check(rc)
+            raise Lcp2Error(rc, self.lib.lcp2_status_str(rc).decode())
+
+    def digest(self):
+        d = np.zeros(4, dtype=np.uint64)
+        cap = np.zeros((1 << self.circ.params.cap_height, 4), dtype=np.uint64)
+        self._check(self.lib.lcp2_circuit_digest(self.handle, _ptr(d), _ptr(cap)))
+        return d, cap
+
+    def prove(self, wires, public_inputs, mem=MEM_HOST):
+        """data.prove(pw): wires = full witness [num_wires][n] (numpy, or a device pointer with mem=MEM_DEVICE)"""
+        pis = _np_u64(public_inputs)
+        proof = np.zeros(self.proof_words, dtype=np.uint64)
+        if mem == MEM_HOST:
+            w = _np_u64(wires)
+            wp = _ptr(w)
+        else:
+            wp = ctypes.c_void_p(wires)
+        self._check(self.lib.lcp2_prove(self.handle, wp, mem, _ptr(pis), _ptr(proof)))
+        return proof
+
+    def verify(self, proof, public_inputs):
+        """data.verify(proof): raises ProofRejected like the reference's unwrap()"""
+        failed = ctypes.c_int(0)
+        pr, pis = _np_u64(proof), _np_u64(public_inputs)
+        rc = self.lib.lcp2_verify(self.handle, _ptr(pr), _ptr(pis), ctypes.byref(failed))
+        if rc == -7:
+            raise ProofRejected(failed.value)
+        self._check(rc)
+
+    def last_challenges(self):
+        out = np.zeros(97, dtype=np.uint64)
+        self._check(self.lib.lcp2_last_challenges(self.handle, _ptr(out)))
+        return {"betas": out[0:4], "gammas": out[4:8], "alphas": out[8:12], "zeta": out[12:14], "fri_alpha": out[14:16],
+                "fri_betas": out[16:32].reshape(8, 2), "pow_witness": int(out[32]), "query_indices": out[33:97]}
+
+    def close(self):
+        if self.handle:
+            self.lib.lcp2_circuit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

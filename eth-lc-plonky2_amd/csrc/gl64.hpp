@@ -13,6 +13,7 @@
 #include <stddef.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define LCP2_HD __host__ __device__ __forceinline__
 #else
 #define LCP2_HD inline

@@ -67,6 +67,8 @@ struct DevBuf {
     if (e == hipSuccess) bytes = n; else p = nullptr;
     return e;
   }
+  // keep the allocation if it is already large enough (persistent prover workspaces)
+  hipError_t ensure(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(n); }
   void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
   u64 *u() const { return (u64 *)p; }
 };

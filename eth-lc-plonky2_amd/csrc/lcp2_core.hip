@@ -211,8 +211,8 @@ int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
   o->level_off.resize(nlev);
   u64 total = 0;
   for (u32 l = 0; l < nlev; l++) { o->level_off[l] = total; total += N >> l; }
-  LCP2_HIP(ctx, o->digests.alloc(total * 4 * sizeof(u64)));
-  LCP2_HIP(ctx, o->d_level_off.alloc(nlev * sizeof(u64)));
+  LCP2_HIP(ctx, o->digests.ensure(total * 4 * sizeof(u64)));
+  LCP2_HIP(ctx, o->d_level_off.ensure(nlev * sizeof(u64)));
   LCP2_HIP(ctx, hipMemcpyAsync(o->d_level_off.p, o->level_off.data(), nlev * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
   {
     ProfScope ps(ctx, LCP2_K_LEAF_HASH, (double)N * (8.0 * o->ncols + 32.0));
@@ -229,7 +229,7 @@ int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
 
 static int lde_and_merkle(lcp2_ctx *ctx, lcp2_oracle *o) {
   const u64 n = (u64)1 << o->log_n, N = o->nleaves();
-  LCP2_HIP(ctx, o->lde.alloc((size_t)o->ncols * N * sizeof(u64)));
+  LCP2_HIP(ctx, o->lde.ensure((size_t)o->ncols * N * sizeof(u64)));
   DeviceNttBackend be{ctx};
   NttHost<DeviceNttBackend> ntt(be);
   {
@@ -246,7 +246,7 @@ int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t l
   if (cap_height > log_n + rate_bits || ncols == 0 || ncols > 65535) return ctx->fail(LCP2_E_INVALID, "commit: bad shape");
   o->ctx = ctx; o->ncols = (uint32_t)ncols; o->log_n = log_n; o->rate_bits = rate_bits; o->cap_height = cap_height;
   const u64 n = (u64)1 << log_n;
-  LCP2_HIP(ctx, o->coeffs.alloc(ncols * n * sizeof(u64)));
+  LCP2_HIP(ctx, o->coeffs.ensure(ncols * n * sizeof(u64)));
   DeviceNttBackend be{ctx};
   NttHost<DeviceNttBackend> ntt(be);
   {
@@ -263,9 +263,9 @@ int commit_coeffs_dev(lcp2_ctx *ctx, const u64 *d_coeffs, size_t ncols, uint32_t
   if (cap_height > log_n + rate_bits || ncols == 0 || ncols > 65535) return ctx->fail(LCP2_E_INVALID, "commit: bad shape");
   o->ctx = ctx; o->ncols = (uint32_t)ncols; o->log_n = log_n; o->rate_bits = rate_bits; o->cap_height = cap_height;
   const u64 n = (u64)1 << log_n;
-  (void)take_copy;
-  LCP2_HIP(ctx, o->coeffs.alloc(ncols * n * sizeof(u64)));
-  LCP2_HIP(ctx, hipMemcpyAsync(o->coeffs.p, d_coeffs, ncols * n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+  LCP2_HIP(ctx, o->coeffs.ensure(ncols * n * sizeof(u64)));
+  if (take_copy && d_coeffs != o->coeffs.u())  // take_copy = false: the caller already wrote o->coeffs in place
+    LCP2_HIP(ctx, hipMemcpyAsync(o->coeffs.p, d_coeffs, ncols * n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
   return lde_and_merkle(ctx, o);
 }
 }  // namespace lcp2

@@ -1,0 +1,569 @@
+// Host orchestration of the prover: lcp2_circuit_create (= build()), lcp2_prove (= data.prove(pw)).
+//
+// Follows plonky2 0.1.4 plonk/prover.rs::prove step by step; every heavy step is a
+// kernel from kernels_*.hip on the context's stream.  The Fiat-Shamir challenger (row a14: a few hundred
+// permutations) runs on the host between the commitments; it needs only the 512-byte caps, the opening
+// values and the final polynomial, which are the only device-to-host copies before the query phase.
+#include <cstring>
+#include "host_protocol.hpp"
+#include "internal.hpp"
+#include "ntt_host.hpp"
+#include "prover_kernels.hpp"
+
+using namespace lcp2;
+
+struct lcp2_circuit {
+  lcp2_ctx *ctx = nullptr;
+  lcp2_params p{};
+  uint32_t npi = 0, num_selectors = 0, num_regs = 1;
+  std::vector<lcp2_gate> gates;
+  std::vector<uint32_t> code;
+  std::vector<u64> imm, k_is;
+  u64 digest[4] = {0, 0, 0, 0};
+  std::vector<u64> cs_cap;
+  u64 last_challenges[97] = {0};
+  // device: description
+  DevBuf d_gates, d_code, d_imm, d_kis, d_l0, d_zh_inv, cs_values;
+  lcp2_oracle cs;  // constants_sigmas commitment
+  // device: per-proof workspace (allocated once)
+  lcp2_oracle wires, zs, quot;
+  DevBuf wires_vals, zs_vals, chunk_q, row_tot, scan_tmp, qvals, planes, small, partial, tables;
+  DevBuf fri_c[2];                       // ping-pong coefficient planes [2][m]
+  std::vector<DevBuf> fri_vals, fri_dig; // per layer: value planes [2][8 m_l], digests
+  std::vector<std::vector<u64>> fri_level_off;
+  std::vector<DevBuf> fri_d_level_off;
+  DevBuf q_idx, q_buf;
+};
+
+namespace {
+#define LCP2_TRY(expr) do { int rc_ = (expr); if (rc_ != LCP2_OK) return rc_; } while (0)
+
+inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
+
+int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
+  if (p.degree_bits < 1 || p.degree_bits + p.rate_bits > 30) return ctx->fail(LCP2_E_INVALID, "degree_bits out of range");
+  if (p.quotient_degree_factor != (1u << p.rate_bits)) return ctx->fail(LCP2_E_UNSUPPORTED, "quotient_degree_factor must equal 2^rate_bits");
+  if (p.num_challenges < 1 || p.num_challenges > QUOTIENT_MAX_CH) return ctx->fail(LCP2_E_UNSUPPORTED, "num_challenges must be 1 or 2");
+  if (p.num_routed_wires > p.num_wires || p.num_routed_wires == 0) return ctx->fail(LCP2_E_INVALID, "bad routed wire count");
+  if ((p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor > PERM_MAX_CHUNKS) return ctx->fail(LCP2_E_UNSUPPORTED, "too many routed wires");
+  if (p.cap_height > p.degree_bits + p.rate_bits) return ctx->fail(LCP2_E_INVALID, "cap_height exceeds the LDE tree");
+  if (p.num_query_rounds > 64 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS) return ctx->fail(LCP2_E_UNSUPPORTED, "too many queries / layers");
+  if (p.proof_of_work_bits < 1 || p.proof_of_work_bits > 40) return ctx->fail(LCP2_E_UNSUPPORTED, "proof_of_work_bits out of range");
+  u32 lg = p.degree_bits + p.rate_bits, d = p.degree_bits;
+  for (u32 l = 0; l < p.num_fri_layers; l++) {
+    u32 ab = p.fri_arity_bits[l];
+    if (ab < 1 || ab > 5 || ab > d || lg - ab < p.cap_height) return ctx->fail(LCP2_E_INVALID, "bad FRI arity schedule");
+    lg -= ab; d -= ab;
+  }
+  return LCP2_OK;
+}
+
+int upload(lcp2_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
+  LCP2_HIP(ctx, b.ensure(bytes));
+  if (bytes) LCP2_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return LCP2_OK;
+}
+int download(lcp2_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  LCP2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
+
+// two-level extension power tables: lo[j] = z^j (j < 2^h), hi[j] = z^(j << h) (j <= count >> h), interleaved [c0, c1]
+void ext_pow_tables(gl2 z, u32 h, u64 hi_count, std::vector<u64> &out, size_t &lo_off, size_t &hi_off) {
+  lo_off = out.size();
+  gl2 cur = gl2_make(1, 0);
+  for (u64 j = 0; j < (1ull << h); j++) { out.push_back(cur.c0); out.push_back(cur.c1); cur = gl2_mul(cur, z); }
+  hi_off = out.size();
+  gl2 step = cur;  // z^(2^h)
+  cur = gl2_make(1, 0);
+  for (u64 j = 0; j < hi_count; j++) { out.push_back(cur.c0); out.push_back(cur.c1); cur = gl2_mul(cur, step); }
+}
+}  // namespace
+
+// ------------------------------------------------------------------ build()
+extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lcp2_circuit **out) {
+  if (!ctx || !d || !out) return LCP2_E_INVALID;
+  *out = nullptr;
+  if (!d->constants_sigmas || !d->k_is || !d->gates || !d->code || (d->num_imm && !d->imm)) return ctx->fail(LCP2_E_INVALID, "null description field");
+  LCP2_TRY(check_params(ctx, d->params));
+  const lcp2_params &p = d->params;
+  if (d->num_selectors > p.num_constants || d->num_regs > 64 || d->num_gates == 0) return ctx->fail(LCP2_E_INVALID, "bad gate set");
+  if (d->num_public_inputs > 4096) return ctx->fail(LCP2_E_UNSUPPORTED, "too many public inputs");
+  // validate the programs once so that the kernels never index out of range
+  for (u32 g = 0; g < d->num_gates; g++) {
+    const lcp2_gate &G = d->gates[g];
+    if (G.selector_index >= d->num_selectors || (size_t)(G.code_offset + G.code_len) * 2 > d->code_words || G.group_end < G.group_start)
+      return ctx->fail(LCP2_E_INVALID, "gate descriptor out of range");
+    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
+      u32 w0 = d->code[2 * pc], w1 = d->code[2 * pc + 1];
+      u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, kk[2] = {(w0 >> 16) & 0xF, (w0 >> 20) & 0xF}, ii[2] = {w1 & 0xFFFF, w1 >> 16};
+      if (op > 3 || (op != 3 && dst >= std::max(d->num_regs, 1u))) return ctx->fail(LCP2_E_INVALID, "bad instruction");
+      for (int s = 0; s < (op == 3 ? 1 : 2); s++) {
+        u32 lim = kk[s] == 0 ? std::max(d->num_regs, 1u) : kk[s] == 1 ? p.num_wires : kk[s] == 2 ? p.num_constants - d->num_selectors
+                  : kk[s] == 3 ? (u32)d->num_imm : kk[s] == 4 ? d->num_public_inputs : 0;
+        if (ii[s] >= lim) return ctx->fail(LCP2_E_INVALID, "operand out of range");
+      }
+    }
+  }
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<lcp2_circuit> c(new lcp2_circuit());
+  c->ctx = ctx; c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
+  c->gates.assign(d->gates, d->gates + d->num_gates);
+  c->code.assign(d->code, d->code + d->code_words);
+  c->imm.resize(std::max<size_t>(d->num_imm, 1), 0);
+  for (size_t i = 0; i < d->num_imm; i++) c->imm[i] = gl_canon(d->imm[i]);
+  c->k_is.resize(p.num_routed_wires);
+  for (u32 i = 0; i < p.num_routed_wires; i++) c->k_is[i] = gl_canon(d->k_is[i]);
+  const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits;
+  const u32 ncs = p.num_constants + p.num_routed_wires, CH = p.num_challenges, npp = npp_of(p), nchunks = npp + 1;
+  LCP2_TRY(upload(ctx, c->d_gates, c->gates.data(), c->gates.size() * sizeof(lcp2_gate)));
+  LCP2_TRY(upload(ctx, c->d_code, c->code.data(), c->code.size() * 4));
+  LCP2_TRY(upload(ctx, c->d_imm, c->imm.data(), c->imm.size() * 8));
+  LCP2_TRY(upload(ctx, c->d_kis, c->k_is.data(), c->k_is.size() * 8));
+  // constants_sigmas values stay resident (K5 reads the sigma columns on H)
+  LCP2_HIP(ctx, c->cs_values.alloc((size_t)ncs * n * 8));
+  LCP2_HIP(ctx, hipMemcpyAsync(c->cs_values.p, d->constants_sigmas, (size_t)ncs * n * 8,
+                               d->constants_sigmas_mem == LCP2_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  LCP2_TRY(commit_values_dev(ctx, c->cs_values.u(), ncs, p.degree_bits, p.rate_bits, p.cap_height, &c->cs));
+  const size_t capw = (size_t)4 << p.cap_height;
+  c->cs_cap.resize(capw);
+  LCP2_TRY(download(ctx, c->cs_cap.data(), c->cs.cap_dev(), capw * 8));
+  {  // circuit digest = H(constants_sigmas_cap || degree_bits)
+    std::vector<u64> buf(c->cs_cap);
+    buf.push_back(p.degree_bits);
+    HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), c->digest);
+  }
+  // L_0 on the LDE points (leaf order): LDE of the polynomial with all coefficients 1/n
+  {
+    DevBuf ones;
+    LCP2_HIP(ctx, ones.alloc(n * 8));
+    launch_fill(ctx->stream, ones.u(), n, gl_inv(n % GL_P));
+    LCP2_HIP(ctx, c->d_l0.alloc(N * 8));
+    DeviceNttBackend be{ctx};
+    NttHost<DeviceNttBackend> ntt(be);
+    ntt.forward(ones.u(), n, c->d_l0.u(), N, p.degree_bits, 1, GL_GENERATOR, p.rate_bits);
+    if (be.status) return be.status;
+    LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  {  // 1 / Z_H(7 w_N^j) depends on j mod 2^rate_bits = bitrev of the top rate_bits of the leaf index
+    std::vector<u64> t(1u << p.rate_bits);
+    u64 shift_n = gl_pow(GL_GENERATOR, n), wr = gl_root_of_unity(p.rate_bits);
+    for (u32 top = 0; top < (1u << p.rate_bits); top++) {
+      u32 r = bitrev32(top, p.rate_bits);
+      t[top] = gl_inv(gl_sub(gl_mul(shift_n, gl_pow(wr, r)), 1));
+    }
+    LCP2_TRY(upload(ctx, c->d_zh_inv, t.data(), t.size() * 8));
+  }
+  // per-proof workspace
+  LCP2_HIP(ctx, c->zs_vals.alloc((size_t)CH * (1 + npp) * n * 8));
+  LCP2_HIP(ctx, c->chunk_q.alloc((size_t)CH * nchunks * n * 8));
+  LCP2_HIP(ctx, c->row_tot.alloc((size_t)CH * n * 8));
+  LCP2_HIP(ctx, c->scan_tmp.alloc(std::max(scan_scratch_words(n, 4), (u64)16) * 8));
+  LCP2_HIP(ctx, c->qvals.alloc((size_t)CH * N * 8));
+  LCP2_HIP(ctx, c->planes.alloc((size_t)4 * n * 8));
+  LCP2_HIP(ctx, c->small.alloc(4096 * 8));
+  {
+    u32 maxcols = std::max(std::max(ncs, p.num_wires), std::max(CH * (1 + npp), CH * p.quotient_degree_factor));
+    u64 nchk = (n + EVAL_CHUNK - 1) / EVAL_CHUNK;
+    LCP2_HIP(ctx, c->partial.alloc((size_t)maxcols * nchk * 16 + (size_t)maxcols * 16));
+  }
+  LCP2_HIP(ctx, c->tables.alloc(((size_t)8 * ((1ull << ((p.degree_bits + 1) / 2)) + (n >> ((p.degree_bits + 1) / 2)) + 2) + 4 * 1024 + 2 * (ncs + p.num_wires + 64) + 64) * 16));
+  LCP2_HIP(ctx, c->fri_c[0].alloc((size_t)2 * n * 8));
+  LCP2_HIP(ctx, c->fri_c[1].alloc((size_t)2 * n * 8));
+  {
+    u64 m = n;
+    c->fri_vals.resize(p.num_fri_layers); c->fri_dig.resize(p.num_fri_layers);
+    c->fri_level_off.resize(p.num_fri_layers); c->fri_d_level_off.resize(p.num_fri_layers);
+    for (u32 l = 0; l < p.num_fri_layers; l++) {
+      u64 nvals = m << p.rate_bits, nleaves = nvals >> p.fri_arity_bits[l];
+      u32 h = 0;
+      while ((1ull << h) < nleaves) h++;
+      u32 nlev = h - p.cap_height + 1;
+      LCP2_HIP(ctx, c->fri_vals[l].alloc((size_t)2 * nvals * 8));
+      c->fri_level_off[l].resize(nlev);
+      u64 tot = 0;
+      for (u32 k = 0; k < nlev; k++) { c->fri_level_off[l][k] = tot; tot += nleaves >> k; }
+      LCP2_HIP(ctx, c->fri_dig[l].alloc(tot * 32));
+      LCP2_TRY(upload(ctx, c->fri_d_level_off[l], c->fri_level_off[l].data(), nlev * 8));
+      m >>= p.fri_arity_bits[l];
+    }
+  }
+  LCP2_HIP(ctx, c->q_idx.alloc(64 * 8 * (2 + LCP2_MAX_FRI_LAYERS)));
+  LCP2_HIP(ctx, c->q_buf.alloc((size_t)64 * (ncs + p.num_wires + CH * (1 + npp) + CH * p.quotient_degree_factor + 4 * 4 * 32 + LCP2_MAX_FRI_LAYERS * (64 + 4 * 32)) * 8));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = c.release();
+  return LCP2_OK;
+}
+
+extern "C" int lcp2_verifier_create(const lcp2_circuit_desc *d, const uint64_t digest[4], const uint64_t *cap, lcp2_circuit **out) {
+  if (!d || !digest || !cap || !out || !d->k_is || !d->gates || !d->code) return LCP2_E_INVALID;
+  *out = nullptr;
+  const lcp2_params &p = d->params;
+  if (p.num_challenges < 1 || p.num_challenges > 4 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS || p.num_query_rounds > 64 ||
+      p.num_routed_wires > p.num_wires || d->num_selectors > p.num_constants)
+    return LCP2_E_INVALID;
+  for (u32 g = 0; g < d->num_gates; g++)
+    if ((size_t)(d->gates[g].code_offset + d->gates[g].code_len) * 2 > d->code_words) return LCP2_E_INVALID;
+  lcp2_circuit *c = new lcp2_circuit();
+  c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
+  c->gates.assign(d->gates, d->gates + d->num_gates);
+  c->code.assign(d->code, d->code + d->code_words);
+  c->imm.resize(std::max<size_t>(d->num_imm, 1), 0);
+  for (size_t i = 0; i < d->num_imm; i++) c->imm[i] = gl_canon(d->imm[i]);
+  c->k_is.resize(p.num_routed_wires);
+  for (u32 i = 0; i < p.num_routed_wires; i++) c->k_is[i] = gl_canon(d->k_is[i]);
+  memcpy(c->digest, digest, 32);
+  c->cs_cap.assign((const u64 *)cap, (const u64 *)cap + ((size_t)4 << p.cap_height));
+  *out = c;
+  return LCP2_OK;
+}
+
+extern "C" void lcp2_circuit_destroy(lcp2_circuit *c) {
+  if (!c) return;
+  if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+  delete c;
+}
+extern "C" int lcp2_circuit_digest(const lcp2_circuit *c, uint64_t digest[4], uint64_t *cap) {
+  if (!c || !digest) return LCP2_E_INVALID;
+  memcpy(digest, c->digest, 32);
+  if (cap) memcpy(cap, c->cs_cap.data(), c->cs_cap.size() * 8);
+  return LCP2_OK;
+}
+extern "C" size_t lcp2_proof_words(const lcp2_params *p) {
+  if (!p) return 0;
+  return ProofLayout(*p).total;
+}
+extern "C" int lcp2_last_challenges(const lcp2_circuit *c, uint64_t out[97]) {
+  if (!c || !out) return LCP2_E_INVALID;
+  memcpy(out, c->last_challenges, sizeof c->last_challenges);
+  return LCP2_OK;
+}
+
+// host-side accessors for the verifier (verifier.hip)
+namespace lcp2 {
+VerifierView verifier_view(const lcp2_circuit *c) {
+  VerifierView v;
+  v.p = &c->p; v.npi = c->npi; v.num_selectors = c->num_selectors;
+  v.gates = c->gates.data(); v.num_gates = (u32)c->gates.size(); v.code = c->code.data(); v.imm = c->imm.data();
+  v.k_is = c->k_is.data(); v.digest = c->digest; v.cs_cap = c->cs_cap.data();
+  return v;
+}
+}  // namespace lcp2
+
+// ------------------------------------------------------------------ prove()
+namespace {
+int open_oracle(lcp2_ctx *ctx, lcp2_oracle &o, const u64 *d_idx, u32 k, u64 *d_leaves, u64 *d_sib) {
+  launch_gather_rows(ctx->stream, o.lde.u(), o.nleaves(), o.ncols, d_idx, k, d_leaves);
+  launch_gather_digests(ctx->stream, o.digests.u(), (const u64 *)o.d_level_off.p, o.nlevels() - 1, d_idx, k, d_sib);
+  return LCP2_OK;
+}
+
+// evaluate every coefficient column of `o` (or its first `ncols`) at z; results (ext) land in d_out[2 * ncols]
+int eval_columns(lcp2_circuit *c, const u64 *coeffs, u32 ncols, gl2 z, u64 *d_out, u64 *d_tab) {
+  lcp2_ctx *ctx = c->ctx;
+  const u64 n = 1ull << c->p.degree_bits;
+  EvalArgs a{};
+  a.coeffs = coeffs; a.col_stride = n;
+  a.chunk_len = (u32)std::min<u64>(n, EVAL_CHUNK);
+  a.items = (a.chunk_len + 255) / 256;
+  a.nchunks = (u32)(n / a.chunk_len);
+  std::vector<u64> t;
+  gl2 cur = gl2_make(1, 0);
+  for (int i = 0; i < 256; i++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, z); }
+  a.zstep[0] = cur.c0; a.zstep[1] = cur.c1;  // z^256
+  gl2 zc = gl2_pow(z, a.chunk_len);
+  cur = gl2_make(1, 0);
+  for (u32 k = 0; k < a.nchunks; k++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, zc); }
+  LCP2_HIP(ctx, hipMemcpyAsync(d_tab, t.data(), t.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `t` is a stack-lifetime staging buffer
+  a.zpow_t = d_tab; a.zpow_chunk = d_tab + 512;
+  a.partial = c->partial.u();
+  launch_eval_polys(ctx->stream, a, ncols, d_out);
+  return LCP2_OK;
+}
+}  // namespace
+
+extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, uint64_t *proof_) {
+  if (!c || !wires_in_ || !proof_ || (c->npi && !public_inputs_)) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;  // verifier-only circuit
+  const u64 *wires_in = (const u64 *)wires_in_, *public_inputs = (const u64 *)public_inputs_;
+  u64 *proof = (u64 *)proof_;
+  lcp2_ctx *ctx = c->ctx;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  const lcp2_params &p = c->p;
+  const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits;
+  const u32 lgN = p.degree_bits + p.rate_bits, W = p.num_wires, NR = p.num_routed_wires, NC = p.num_constants, CH = p.num_challenges,
+            Q = p.quotient_degree_factor, npp = npp_of(p), nchunks = npp + 1, ncs = NC + NR;
+  const ProofLayout L(p);
+  memset(proof, 0, L.total * 8);
+  hipStream_t s = ctx->stream;
+  DeviceNttBackend be{ctx};
+  NttHost<DeviceNttBackend> ntt(be);
+  HostPoseidon &H = HostPoseidon::get();
+
+  std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
+  for (u32 i = 0; i < c->npi; i++) pis[i] = gl_canon(public_inputs[i]);
+  u64 pi_hash[4];
+  H.hash_no_pad(pis.data(), c->npi, pi_hash);
+
+  // small device block: [betas CH | gammas CH | alphas CH | pis]
+  u64 *d_small = c->small.u();
+  u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
+  if (c->npi) LCP2_HIP(ctx, hipMemcpyAsync(d_pis, pis.data(), c->npi * 8, hipMemcpyHostToDevice, s));
+
+  // ---- wires commitment
+  const u64 *d_wires = wires_in;
+  if (wires_mem == LCP2_MEM_HOST) {
+    LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
+    LCP2_HIP(ctx, hipMemcpyAsync(c->wires_vals.p, wires_in, (size_t)W * n * 8, hipMemcpyHostToDevice, s));
+    d_wires = c->wires_vals.u();
+  }
+  LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
+  LCP2_TRY(download(ctx, proof + L.wires_cap, c->wires.cap_dev(), L.capw * 8));
+
+  HostChallenger ch;
+  ch.observe_n(c->digest, 4);
+  ch.observe_n(pi_hash, 4);
+  ch.observe_n(proof + L.wires_cap, L.capw);
+  u64 betas[4] = {0}, gammas[4] = {0}, alphas[4] = {0};
+  for (u32 k = 0; k < CH; k++) betas[k] = ch.get();
+  for (u32 k = 0; k < CH; k++) gammas[k] = ch.get();
+  LCP2_HIP(ctx, hipMemcpyAsync(d_betas, betas, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_gammas, gammas, CH * 8, hipMemcpyHostToDevice, s));
+
+  // ---- K5: Z and partial products on H
+  {
+    PermArgs a{};
+    a.wires = d_wires; a.sigmas = c->cs_values.u() + (u64)NC * n; a.k_is = c->d_kis.u();
+    a.subgroup = ntt.root_table(p.degree_bits, false);
+    a.betas = d_betas; a.gammas = d_gammas; a.chunk_q = c->chunk_q.u(); a.row_tot = c->row_tot.u(); a.zs_out = c->zs_vals.u();
+    a.n = n; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH;
+    if (be.status) return be.status;
+    ProfScope ps(ctx, LCP2_K_PERM_Z, (double)n * 8.0 * (2.0 * NR + CH * (1.0 + npp)));
+    launch_perm_chunks(s, a);
+    launch_scan(s, true, c->row_tot.u(), c->zs_vals.u(), c->scan_tmp.u(), n, false, CH, n);
+    launch_perm_finalize(s, a);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+  LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
+  LCP2_TRY(download(ctx, proof + L.zs_cap, c->zs.cap_dev(), L.capw * 8));
+  ch.observe_n(proof + L.zs_cap, L.capw);
+  for (u32 k = 0; k < CH; k++) alphas[k] = ch.get();
+  LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, alphas, CH * 8, hipMemcpyHostToDevice, s));
+
+  // ---- K6: quotient values on the coset, coset iNTT, chunking, commitment
+  {
+    QuotientArgs a{};
+    a.wires = c->wires.lde.u(); a.consts = c->cs.lde.u(); a.zs = c->zs.lde.u(); a.l0 = c->d_l0.u(); a.zh_inv = c->d_zh_inv.u();
+    u64 ls, hs;
+    a.points = ntt.shift_table(gl_root_of_unity(lgN), lgN, 0, false, GL_GENERATOR, ls, hs);
+    a.k_is = c->d_kis.u(); a.betas = d_betas; a.gammas = d_gammas; a.alphas = d_alphas; a.pis = d_pis; a.imm = c->d_imm.u();
+    a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.out = c->qvals.u();
+    a.N = N; a.lgN = lgN; a.rate_bits = p.rate_bits; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors;
+    a.num_constants = NC; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH; a.num_regs = c->num_regs;
+    if (be.status) return be.status;
+    ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)N * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH));
+    launch_quotient(s, a);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+  LCP2_HIP(ctx, c->quot.coeffs.ensure((size_t)CH * N * 8));
+  {
+    ProfScope ps(ctx, LCP2_K_INTT, 16.0 * N * CH);
+    ntt.inverse_bitrev_in(c->qvals.u(), N, c->quot.coeffs.u(), N, lgN, CH, GL_GENERATOR);
+  }
+  if (be.status) return be.status;
+  // N = Q n: the 8n coefficients of challenge c are exactly its Q chunks of n coefficients, already contiguous
+  LCP2_TRY(commit_coeffs_dev(ctx, c->quot.coeffs.u(), CH * Q, p.degree_bits, p.rate_bits, p.cap_height, &c->quot, false));
+  LCP2_TRY(download(ctx, proof + L.quot_cap, c->quot.cap_dev(), L.capw * 8));
+  ch.observe_n(proof + L.quot_cap, L.capw);
+  const gl2 zeta = ch.get_ext();
+  const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
+
+  // ---- K7a: openings
+  lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+  {
+    u64 *d_tab = c->tables.u();
+    u64 *d_open = c->partial.u() + c->partial.bytes / 8 - 2 * (size_t)std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q));
+    std::vector<u64> tmp(2 * std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q)));
+    ProfScope ps(ctx, LCP2_K_OPENINGS, 8.0 * n * (ncs + W + CH * (1.0 + npp) + CH * Q + CH));
+    for (int o = 0; o < 4; o++) {
+      u32 nc = oracles[o]->ncols;
+      LCP2_TRY(eval_columns(c, oracles[o]->coeffs.u(), nc, zeta, d_open, d_tab));
+      LCP2_TRY(download(ctx, tmp.data(), d_open, 2 * nc * 8));
+      if (o == 0) memcpy(proof + L.op_constants, tmp.data(), 2 * nc * 8);  // constants then sigmas, contiguous
+      else if (o == 1) memcpy(proof + L.op_wires, tmp.data(), 2 * nc * 8);
+      else if (o == 2) { memcpy(proof + L.op_zs, tmp.data(), 2 * CH * 8); memcpy(proof + L.op_pp, tmp.data() + 2 * CH, 2 * CH * npp * 8); }
+      else memcpy(proof + L.op_quot, tmp.data(), 2 * nc * 8);
+    }
+    LCP2_TRY(eval_columns(c, c->zs.coeffs.u(), CH, g_zeta, d_open, d_tab));
+    LCP2_TRY(download(ctx, proof + L.op_zs_next, d_open, 2 * CH * 8));
+  }
+  ch.observe_n(proof + L.op_constants, 2 * (ncs + W));
+  ch.observe_n(proof + L.op_zs, 2 * CH);
+  ch.observe_n(proof + L.op_pp, 2 * CH * npp);
+  ch.observe_n(proof + L.op_quot, 2 * CH * Q);
+  ch.observe_n(proof + L.op_zs_next, 2 * CH);
+
+  // ---- K7b: final polynomial of the batched opening
+  const gl2 alpha = ch.get_ext();
+  {
+    const u32 total_polys = ncs + W + CH * (1 + npp) + CH * Q;
+    const u32 h = (p.degree_bits + 1) / 2;
+    const u64 hi_count = (n >> h) + 1;
+    std::vector<u64> t;
+    gl2 cur = gl2_make(1, 0);
+    for (u32 j = 0; j < total_polys; j++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, alpha); }
+    size_t off[8][2];
+    gl2 bases[4] = {zeta, g_zeta, gl2_inv(zeta), gl2_inv(g_zeta)};
+    for (int b = 0; b < 4; b++) ext_pow_tables(bases[b], h, hi_count, t, off[b][0], off[b][1]);
+    if (t.size() * 8 > c->tables.bytes) return ctx->fail(LCP2_E_INVALID, "internal: table workspace too small");
+    LCP2_HIP(ctx, hipMemcpyAsync(c->tables.p, t.data(), t.size() * 8, hipMemcpyHostToDevice, s));
+    LCP2_HIP(ctx, hipStreamSynchronize(s));
+    ComposeArgs a{};
+    for (int o = 0; o < 4; o++) { a.coeffs[o] = oracles[o]->coeffs.u(); a.ncols[o] = oracles[o]->ncols; }
+    a.num_challenges = CH; a.n = n;
+    const u64 *T = c->tables.u();
+    a.alpha_pows = T;
+    a.z0_lo = T + off[0][0]; a.z0_hi = T + off[0][1]; a.z1_lo = T + off[1][0]; a.z1_hi = T + off[1][1];
+    a.zi0_lo = T + off[2][0]; a.zi0_hi = T + off[2][1]; a.zi1_lo = T + off[3][0]; a.zi1_hi = T + off[3][1];
+    a.zh = h; a.zmask = (1ull << h) - 1;
+    gl2 ash = gl2_pow(alpha, CH);
+    a.alpha_shift[0] = ash.c0; a.alpha_shift[1] = ash.c1;
+    a.planes = c->planes.u();
+    ProfScope ps(ctx, LCP2_K_OPENINGS, 8.0 * n * (total_polys + CH));
+    launch_compose(s, a);
+    launch_scan(s, false, c->planes.u(), c->planes.u(), c->scan_tmp.u(), n, true, 4, n);
+    launch_divide_finalize(s, a, c->fri_c[0].u(), c->fri_c[0].u() + n);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+
+  // ---- K8: FRI commit phase
+  gl2 fri_betas[LCP2_MAX_FRI_LAYERS];
+  u64 m = n;  // number of (possibly) non-zero coefficients; the zero padding to 8m is implicit
+  u64 shift = GL_GENERATOR;
+  int cur = 0;
+  {
+    for (u32 l = 0; l < p.num_fri_layers; l++) {
+      const u32 ab = p.fri_arity_bits[l], arity = 1u << ab;
+      u32 lgm = 0;
+      while ((1ull << lgm) < m) lgm++;
+      const u64 nvals = m << p.rate_bits, nleaves = nvals >> ab;
+      u64 *vals = c->fri_vals[l].u();
+      {
+        ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * nvals + 32.0 * nleaves);
+        // coset_fft of the zero-padded coefficients = 2^rate_bits coset transforms of the m coefficients; leaf order out
+        ntt.forward(c->fri_c[cur].u(), m, vals, nvals, lgm, 2, shift, p.rate_bits);
+        if (be.status) return be.status;
+        launch_hash_ext_leaves(s, vals, vals + nvals, arity, nleaves, c->fri_dig[l].u(), ctx->d_rc);
+        const auto &off = c->fri_level_off[l];
+        for (size_t k = 1; k < off.size(); k++)
+          launch_merkle_level(s, c->fri_dig[l].u() + 4 * off[k - 1], c->fri_dig[l].u() + 4 * off[k], nleaves >> k, ctx->d_rc);
+      }
+      LCP2_HIP(ctx, hipGetLastError());
+      LCP2_TRY(download(ctx, proof + L.fri_caps + l * L.capw, c->fri_dig[l].u() + 4 * c->fri_level_off[l].back(), L.capw * 8));
+      ch.observe_n(proof + L.fri_caps + l * L.capw, L.capw);
+      gl2 beta = ch.get_ext();
+      fri_betas[l] = beta;
+      {
+        ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * (m >> ab));
+        launch_fri_fold(s, c->fri_c[cur].u(), c->fri_c[cur].u() + m, c->fri_c[cur ^ 1].u(), c->fri_c[cur ^ 1].u() + (m >> ab), m >> ab, arity, beta.c0, beta.c1);
+      }
+      cur ^= 1;
+      m >>= ab;
+      shift = gl_pow(shift, arity);
+    }
+  }
+  if (m != L.final_len) return ctx->fail(LCP2_E_INVALID, "internal: final polynomial length mismatch");
+  {
+    std::vector<u64> f(2 * m);
+    LCP2_TRY(download(ctx, f.data(), c->fri_c[cur].u(), 2 * m * 8));
+    for (u64 i = 0; i < m; i++) { proof[L.final_poly + 2 * i] = f[i]; proof[L.final_poly + 2 * i + 1] = f[m + i]; }
+  }
+  ch.observe_n(proof + L.final_poly, 2 * L.final_len);
+
+  // ---- K9: proof of work, minimum witness
+  u64 pow_witness = 0;
+  {
+    PowArgs a{};
+    ch.pow_state(a.state, a.pos);
+    a.bits = p.proof_of_work_bits; a.rc = ctx->d_rc;
+    u64 *d_res = c->small.u() + 1024;
+    a.result = d_res;
+    const u64 batch = 1ull << 20;
+    u64 res = ~0ull;
+    ProfScope ps(ctx, LCP2_K_POW, 0.0);
+    for (u64 start = 0; res == ~0ull; start += batch) {
+      if (start >= (1ull << 44)) return ctx->fail(LCP2_E_UNSUPPORTED, "proof of work not found");
+      LCP2_HIP(ctx, hipMemsetAsync(d_res, 0xFF, 8, s));
+      a.start = start;
+      launch_pow_search(s, a, batch);
+      LCP2_TRY(download(ctx, &res, d_res, 8));
+    }
+    pow_witness = res;
+  }
+  proof[L.pow_witness] = pow_witness;
+  ch.observe(pow_witness);
+  {
+    u64 resp = ch.get();
+    if ((resp >> (64 - p.proof_of_work_bits)) != 0) return ctx->fail(LCP2_E_HIP, "internal: proof-of-work self check failed");
+  }
+
+  // ---- query phase: gather leaves and Merkle paths on the device, one copy back
+  const u32 Qn = p.num_query_rounds;
+  std::vector<u64> idx(Qn * (1 + p.num_fri_layers));
+  for (u32 q = 0; q < Qn; q++) {
+    u64 x = ch.get() % N;
+    idx[q] = x;
+    u64 xi = x;
+    for (u32 l = 0; l < p.num_fri_layers; l++) { xi >>= p.fri_arity_bits[l]; idx[(1 + l) * Qn + q] = xi; }
+  }
+  LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s));
+  {
+    u64 *d_idx = c->q_idx.u();
+    u64 *buf = c->q_buf.u();
+    size_t pos = 0;
+    size_t o_leaf[4], o_sib[4], f_leaf[LCP2_MAX_FRI_LAYERS], f_sib[LCP2_MAX_FRI_LAYERS];
+    for (int o = 0; o < 4; o++) {
+      o_leaf[o] = pos; pos += (size_t)Qn * oracles[o]->ncols;
+      o_sib[o] = pos; pos += (size_t)Qn * L.q_init_sib * 4;
+      LCP2_TRY(open_oracle(ctx, *oracles[o], d_idx, Qn, buf + o_leaf[o], buf + o_sib[o]));
+    }
+    for (u32 l = 0; l < p.num_fri_layers; l++) {
+      const u32 arity = 1u << p.fri_arity_bits[l];
+      u64 nvals = (n >> 0);  // recomputed below
+      nvals = N;
+      for (u32 k = 0; k < l; k++) nvals >>= p.fri_arity_bits[k];
+      f_leaf[l] = pos; pos += (size_t)Qn * 2 * arity;
+      f_sib[l] = pos; pos += (size_t)Qn * L.q_step_sib[l] * 4;
+      launch_gather_ext_leaves(s, c->fri_vals[l].u(), c->fri_vals[l].u() + nvals, arity, d_idx + (1 + l) * Qn, Qn, buf + f_leaf[l]);
+      launch_gather_digests(s, c->fri_dig[l].u(), c->fri_d_level_off[l].u(), (u32)L.q_step_sib[l], d_idx + (1 + l) * Qn, Qn, buf + f_sib[l]);
+    }
+    LCP2_HIP(ctx, hipGetLastError());
+    if (pos * 8 > c->q_buf.bytes) return ctx->fail(LCP2_E_INVALID, "internal: query workspace too small");
+    std::vector<u64> h(pos);
+    LCP2_TRY(download(ctx, h.data(), buf, pos * 8));
+    for (u32 q = 0; q < Qn; q++) {
+      u64 *R = proof + L.queries + (size_t)q * L.query_words;
+      for (int o = 0; o < 4; o++) {
+        u32 nc = oracles[o]->ncols;
+        memcpy(R + L.q_init_off[o], h.data() + o_leaf[o] + (size_t)q * nc, nc * 8);
+        memcpy(R + L.q_init_off[o] + nc, h.data() + o_sib[o] + (size_t)q * L.q_init_sib * 4, L.q_init_sib * 32);
+      }
+      for (u32 l = 0; l < p.num_fri_layers; l++) {
+        const u32 arity = 1u << p.fri_arity_bits[l];
+        memcpy(R + L.q_step_off[l], h.data() + f_leaf[l] + (size_t)q * 2 * arity, 2 * arity * 8);
+        memcpy(R + L.q_step_off[l] + 2 * arity, h.data() + f_sib[l] + (size_t)q * L.q_step_sib[l] * 4, L.q_step_sib[l] * 32);
+      }
+    }
+  }
+  // record the transcript for stage-wise parity tests
+  u64 *lc = c->last_challenges;
+  memset(lc, 0, sizeof c->last_challenges);
+  memcpy(lc, betas, 32); memcpy(lc + 4, gammas, 32); memcpy(lc + 8, alphas, 32);
+  lc[12] = zeta.c0; lc[13] = zeta.c1; lc[14] = alpha.c0; lc[15] = alpha.c1;
+  for (u32 l = 0; l < p.num_fri_layers; l++) { lc[16 + 2 * l] = fri_betas[l].c0; lc[17 + 2 * l] = fri_betas[l].c1; }
+  lc[32] = pow_witness;
+  for (u32 q = 0; q < Qn; q++) lc[33 + q] = idx[q];
+  return LCP2_OK;
+}

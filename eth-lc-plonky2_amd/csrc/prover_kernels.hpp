@@ -1,0 +1,91 @@
+// Argument blocks and launch wrappers of the prover kernels (kernels_prover.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gl64.hpp"
+#include "ntt.hpp"
+
+namespace lcp2 {
+
+constexpr u32 PERM_MAX_CHUNKS = 10;   // ceil(80 routed wires / quotient degree factor 8)
+constexpr u32 QUOTIENT_THREADS = 128;
+constexpr u32 QUOTIENT_MAX_CH = 2;
+constexpr u32 EVAL_CHUNK = 4096;
+
+struct GateDev {  // = lcp2_gate
+  u32 selector_index, selector_value, group_start, group_end, code_offset, code_len, num_constraints;
+};
+
+struct PermArgs {
+  const u64 *wires;    // witness values on H, [num_wires][n]
+  const u64 *sigmas;   // sigma values on H, [num_routed][n]
+  const u64 *k_is;     // [num_routed]
+  TwoLevelTable subgroup;  // w_n^row
+  const u64 *betas, *gammas;  // device, [num_challenges]
+  u64 *chunk_q;        // scratch [num_challenges][nchunks][n]
+  u64 *row_tot;        // scratch [num_challenges][n]
+  u64 *zs_out;         // [num_challenges * (1 + npp)][n]: Z_0.., then partial products per challenge
+  u64 n;
+  u32 num_routed, chunk, nchunks, num_challenges;
+};
+
+struct QuotientArgs {
+  const u64 *wires;   // LDE, leaf order, [num_wires][N]
+  const u64 *consts;  // LDE of constants then sigmas, [num_constants + num_routed][N]
+  const u64 *zs;      // LDE of Z / partial products, [CH * (1 + npp)][N]
+  const u64 *l0;      // L_0 on the LDE points, leaf order [N]
+  const u64 *zh_inv;  // 1 / Z_H per top-bits block of the leaf index, [2^rate_bits]
+  TwoLevelTable points;  // 7 * w_N^j
+  const u64 *k_is, *betas, *gammas, *alphas, *pis, *imm;
+  const u32 *code;
+  const GateDev *gates;
+  u64 *out;           // [CH][N] quotient values, leaf order
+  u64 N;
+  u32 lgN, rate_bits, num_gates, num_selectors, num_constants, num_routed, chunk, nchunks, num_challenges, num_regs;
+};
+
+struct EvalArgs {
+  const u64 *coeffs;  // [npolys][col_stride]
+  u64 col_stride;
+  u32 chunk_len, items, nchunks;
+  u64 zstep[2];            // z^256
+  const u64 *zpow_t;       // z^t, t < 256 (ext, interleaved)
+  const u64 *zpow_chunk;   // z^(chunk * chunk_len)
+  u64 *partial;            // [npolys][nchunks] ext
+};
+
+struct ComposeArgs {
+  const u64 *coeffs[4];
+  u32 ncols[4];
+  u32 num_challenges;
+  u64 n;
+  const u64 *alpha_pows;   // alpha^j ext, j < total polys
+  const u64 *z0_lo, *z0_hi, *z1_lo, *z1_hi;      // zeta^i, (g zeta)^i two-level ext tables
+  const u64 *zi0_lo, *zi0_hi, *zi1_lo, *zi1_hi;  // inverse powers
+  u32 zh;
+  u64 zmask;
+  u64 alpha_shift[2];      // alpha^CH
+  u64 *planes;             // [4][n]
+};
+
+struct PowArgs {
+  u64 state[12];
+  u32 pos, bits;
+  u64 start;
+  const u64 *rc;
+  u64 *result;
+};
+
+void launch_scan(hipStream_t s, bool mul, const u64 *in, u64 *out, u64 *block_tot, u64 n, bool reverse, u32 batches, u64 batch_stride);
+u64 scan_scratch_words(u64 n, u32 batches);
+void launch_perm_chunks(hipStream_t s, const PermArgs &a);
+void launch_perm_finalize(hipStream_t s, const PermArgs &a);
+void launch_quotient(hipStream_t s, const QuotientArgs &a);
+void launch_eval_polys(hipStream_t s, const EvalArgs &a, u32 npolys, u64 *out);
+void launch_compose(hipStream_t s, const ComposeArgs &a);
+void launch_divide_finalize(hipStream_t s, const ComposeArgs &a, u64 *out0, u64 *out1);
+void launch_fri_fold(hipStream_t s, const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, u64 nout, u32 arity, u64 b0, u64 b1);
+void launch_gather_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, const u64 *leaf_idx, u32 k, u64 *out);
+void launch_pow_search(hipStream_t s, const PowArgs &a, u64 count);
+void launch_fill(hipStream_t s, u64 *p, u64 n, u64 v);
+
+}  // namespace lcp2

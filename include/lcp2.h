@@ -139,6 +139,81 @@ int lcp2_oracle_open(lcp2_oracle *o, const uint64_t *indices, size_t k, uint64_t
 /* copies for tests: coefficients [ncols][n] and LDE [ncols][n << rate_bits] (leaf order), host buffers */
 int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs /* nullable */, uint64_t *lde /* nullable */);
 
+/* ------------------------------------------------------------------ circuit, prove, verify
+ * The boundary the reference calls (src/main.rs:226-233, src/unit_tests.rs:29-35):
+ *     let data = builder.build::<C>();          -> lcp2_circuit_create
+ *     let proof = data.prove(pw).unwrap();      -> lcp2_prove
+ *     data.verify(proof)                        -> lcp2_verify
+ * A circuit is what build() produces: preprocessed polynomials (selector and
+ * constant columns, sigma polynomials) and the gate set.  plonky2's gate types
+ * are Rust objects that cannot cross a C ABI, so each gate type is described by a
+ * constraint program ("gate program") that the quotient kernel (K6) and the
+ * verifier interpret:
+ *     instruction = 2 words:  w0 = op | dst << 8 | kind_a << 16 | kind_b << 20,  w1 = idx_a | idx_b << 16
+ *     op   0 ADD  1 SUB  2 MUL (dst <- a op b)   3 EMIT (acc <- acc * alpha + a)
+ *     kind 0 REG  1 WIRE (local wire)  2 CONST (gate constant, after the selector columns)
+ *          3 IMM (imm[idx])  4 PI (public_inputs[idx])
+ * A gate lists its constraints from the LAST to the FIRST (EMIT is a Horner step).
+ * Selectors follow plonky2 gates/selectors.rs: gate g is active on rows where
+ * constants[selector_index] == selector_value; its filter is
+ *     prod_{j in [group_start, group_end), j != selector_value} (j - s) * (num_selectors > 1 ? (2^32 - 1 - s) : 1). */
+typedef struct {
+  uint32_t selector_index, selector_value, group_start, group_end;
+  uint32_t code_offset, code_len; /* in instructions */
+  uint32_t num_constraints;
+} lcp2_gate;
+
+typedef struct {
+  lcp2_params params;
+  /* VALUES on the subgroup H, natural row order, column-major [num_constants + num_routed_wires][n]:
+   * selector columns, gate-constant columns, then sigma_j(w^i) = k_{j'} w^{i'} of the copy-constraint permutation */
+  const uint64_t *constants_sigmas;
+  lcp2_mem constants_sigmas_mem;
+  const uint64_t *k_is;            /* host, [num_routed_wires] coset shifts of the permutation argument */
+  uint32_t num_selectors;
+  uint32_t num_gates;
+  const lcp2_gate *gates;          /* host */
+  const uint32_t *code;            /* host, 2 words per instruction */
+  size_t code_words;
+  const uint64_t *imm;             /* host */
+  size_t num_imm;
+  uint32_t num_public_inputs;      /* bound by the PublicInput gate program through kind PI */
+  uint32_t num_regs;               /* registers the programs use (<= 64) */
+} lcp2_circuit_desc;
+
+typedef struct lcp2_circuit lcp2_circuit; /* = CircuitData: prover_only + verifier_only + common */
+
+/* build(): uploads the description, commits constants_sigmas (PolynomialBatch::from_values),
+ * derives the circuit digest and allocates the per-proof workspace in HBM. */
+int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, lcp2_circuit **out);
+void lcp2_circuit_destroy(lcp2_circuit *c);
+/* circuit_digest (4 elements) and constants_sigmas_cap (2^cap_height * 4), host buffers, cap nullable */
+int lcp2_circuit_digest(const lcp2_circuit *c, uint64_t digest[4], uint64_t *cap);
+
+/* Size in uint64_t words of a proof (layout documented in DESIGN.md, same field order as plonky2's
+ * ProofWithPublicInputs: wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap, openings,
+ * opening_proof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness }). */
+size_t lcp2_proof_words(const lcp2_params *p);
+
+/* data.prove(pw): wires is the full witness (generate_partial_witness output), column-major
+ * [num_wires][n]; public_inputs and proof are host buffers.  The proof-of-work witness is the
+ * smallest valid one (plonky2 searches with a nondeterministic find_any). */
+int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const uint64_t *public_inputs, uint64_t *proof);
+
+/* data.verify(proof): host only (no device work).  LCP2_OK or LCP2_E_VERIFY; *failed_check (nullable):
+ * 1 encoding, 2 proof of work, 3 vanishing identity, 4 initial Merkle proof, 5 FRI consistency,
+ * 6 FRI layer Merkle proof, 7 final polynomial. */
+int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, const uint64_t *public_inputs, int *failed_check);
+
+/* Verifier-only circuit (VerifierCircuitData): no device, no context.  Takes the gate set, k_is and
+ * parameters from `desc` (constants_sigmas is ignored and may be NULL) plus the circuit digest and the
+ * constants_sigmas cap published by the prover's build().  lcp2_prove on it returns LCP2_E_NODEVICE. */
+int lcp2_verifier_create(const lcp2_circuit_desc *desc, const uint64_t digest[4], const uint64_t *cap, lcp2_circuit **out);
+
+/* challenges of the last lcp2_prove (for stage-wise parity tests): betas[4], gammas[4], alphas[4], zeta[2],
+ * fri_alpha[2], fri_betas[8][2], pow_witness, query_indices[64] -- 4+4+4+2+2+16+1+64 = 97 words */
+int lcp2_last_challenges(const lcp2_circuit *c, uint64_t out[97]);
+
 /* ------------------------------------------------------------------ timing
  * Per-kernel-family HIP-event timing on the context's stream.  Accumulates
  * while enabled; lcp2_prof_get synchronises and reports totals since the last reset. */

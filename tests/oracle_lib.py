@@ -57,6 +57,14 @@ def load():
         "orc_ifft_batch": (None, [V, c.c_size_t, c.c_size_t]),
         "orc_fft_batch": (None, [V, c.c_size_t, c.c_size_t]),
         "orc_lde_batch": (None, [V, c.c_size_t, c.c_size_t, c.c_uint, c.c_uint64, V]),
+        "orc_circuit_new": (V, [V, V, V, c.c_uint32, V, c.c_uint32, V, c.c_size_t, V, c.c_size_t, c.c_uint32]),
+        "orc_circuit_free": (None, [V]),
+        "orc_circuit_digest": (None, [V, V, V]),
+        "orc_proof_words": (c.c_size_t, [V]),
+        "orc_prove": (c.c_int, [V, V, V, V]),
+        "orc_verify": (c.c_int, [V, V, V]),
+        "orc_check_witness": (c.c_size_t, [V, V, V, V]),
+        "orc_last_challenges": (None, [V, V]),
         "orc_gl_mul": (c.c_uint64, [c.c_uint64, c.c_uint64]),
         "orc_gl_add": (c.c_uint64, [c.c_uint64, c.c_uint64]),
         "orc_gl_sub": (c.c_uint64, [c.c_uint64, c.c_uint64]),
@@ -131,3 +139,52 @@ def merkle_verify(L, leaf, index, siblings, cap):
     siblings = np.ascontiguousarray(siblings, dtype=np.uint64)
     cap = np.ascontiguousarray(cap, dtype=np.uint64)
     return bool(L.orc_merkle_verify(vp(leaf), leaf.size, int(index), vp(siblings), siblings.shape[0], vp(cap)))
+
+
+class OracleChallenges(c.Structure):
+    _fields_ = [("betas", c.c_uint64 * 4), ("gammas", c.c_uint64 * 4), ("alphas", c.c_uint64 * 4), ("zeta", c.c_uint64 * 2),
+                ("fri_alpha", c.c_uint64 * 2), ("fri_betas", (c.c_uint64 * 2) * 8), ("pow_witness", c.c_uint64),
+                ("query_indices", c.c_uint64 * 64)]
+
+
+class OracleCircuit:
+    """orc_circuit built from an eth_lc_plonky2_amd.circuit.Circuit (the same description the GPU prover consumes)."""
+
+    def __init__(self, L, circ):
+        self.L, self.circ = L, circ
+        gs = circ.gateset
+        self.params = circ.params
+        self.h = L.orc_circuit_new(c.byref(circ.params), vp(circ.constants_sigmas), vp(circ.k_is), gs.num_selectors,
+                                   c.cast(circ.gates_array, c.c_void_p), len(gs.gates), vp(gs.code), gs.code_len, vp(gs.imm),
+                                   gs.imm.size, circ.num_public_inputs)
+        assert self.h, "orc_circuit_new rejected the description"
+        self.proof_words = L.orc_proof_words(c.byref(circ.params))
+
+    def check_witness(self, wires, pis):
+        bad = np.zeros(2, dtype=np.uint64)
+        return self.L.orc_check_witness(self.h, vp(np.ascontiguousarray(wires)), vp(np.ascontiguousarray(pis)), vp(bad)), bad
+
+    def prove(self, wires, pis):
+        proof = np.zeros(self.proof_words, dtype=np.uint64)
+        rc = self.L.orc_prove(self.h, vp(np.ascontiguousarray(wires, dtype=np.uint64)), vp(np.ascontiguousarray(pis, dtype=np.uint64)), vp(proof))
+        assert rc == 0
+        return proof
+
+    def verify(self, proof, pis):
+        return self.L.orc_verify(self.h, vp(np.ascontiguousarray(proof, dtype=np.uint64)), vp(np.ascontiguousarray(pis, dtype=np.uint64)))
+
+    def digest(self):
+        d = np.zeros(4, dtype=np.uint64)
+        cap = np.zeros((1 << self.params.cap_height, 4), dtype=np.uint64)
+        self.L.orc_circuit_digest(self.h, vp(d), vp(cap))
+        return d, cap
+
+    def challenges(self):
+        ch = OracleChallenges()
+        self.L.orc_last_challenges(self.h, c.byref(ch))
+        return ch
+
+    def close(self):
+        if self.h:
+            self.L.orc_circuit_free(self.h)
+            self.h = None
