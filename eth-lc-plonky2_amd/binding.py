@@ -47,6 +47,25 @@ class CircuitDesc(ctypes.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so.  Two HIP runtimes in one
+    process cannot both own the GPU, and torch tensors / streams are only meaningful to the runtime that made
+    them, so when torch is installed its runtime is loaded first (RTLD_GLOBAL): liblcp2.so's dependency on
+    SONAME libamdhip64.so.7 then binds to that same copy.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library():
     """Loads (building if the sources are newer) eth-lc-plonky2_amd/liblcp2.so."""
     global _lib
@@ -55,6 +74,7 @@ def load_library():
     path = _build.LIB
     if not os.path.exists(path):
         path = _build.build_native()
+    _share_torch_hip_runtime()
     lib = ctypes.CDLL(path)
     c = ctypes
     sigs = {

@@ -214,7 +214,13 @@ class Circuit:
 def sigma_values(sig_row, sig_col, k_is, degree_bits):
     """sigma_j(w^i) = k_{j'} * w^{i'} for the cell (i', j') that follows (i, j) in its copy cycle"""
     sub = gl.powers(gl.root_of_unity(degree_bits), 1 << degree_bits)
-    return gl.mul(np.asarray(k_is, dtype=np.uint64)[sig_col], sub[sig_row])
+    k_is = np.asarray(k_is, dtype=np.uint64)
+    out = np.empty(sig_row.shape, dtype=np.uint64)
+    step = 1 << 16  # cache-sized pieces: the temporaries of gl.mul stay in L2
+    for j in range(sig_row.shape[0]):
+        for a in range(0, sig_row.shape[1], step):
+            out[j, a:a + step] = gl.mul(k_is[sig_col[j, a:a + step]], sub[sig_row[j, a:a + step]])
+    return out
 
 
 def standard_gateset(npi):
