@@ -65,6 +65,36 @@ LCP2_HD u64 gl_reduce128(u64 lo, u64 hi) {
   if (r < t0) r += GL_EPS;
   return gl_canon(r);
 }
+// ---- lazy forms: results are any u64 congruent to the field element (used inside Poseidon, where only the
+// final state is canonicalised).  Inputs of gl_mul_nc / gl_sqr_nc may be any u64.
+LCP2_HD u64 gl_reduce128_nc(u64 lo, u64 hi) {
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t1 = (hi_lo << 32) - hi_lo;
+  u64 r = t0 + t1;
+  if (r < t0) r += GL_EPS;
+  return r;
+}
+LCP2_HD u64 gl_mul_nc(u64 a, u64 b) {
+  u64 lo, hi;
+  gl_mul_wide(a, b, lo, hi);
+  return gl_reduce128_nc(lo, hi);
+}
+// a^2 with three 32x32 products instead of four
+LCP2_HD u64 gl_sqr_nc(u64 a) {
+  u64 a0 = (u32)a, a1 = a >> 32;
+  u64 p00 = a0 * a0, p01 = a0 * a1, p11 = a1 * a1;
+  u64 lo = p00 + (p01 << 33);
+  u64 hi = p11 + (p01 >> 31) + (lo < p00 ? 1 : 0);
+  return gl_reduce128_nc(lo, hi);
+}
+// a: any u64, b: canonical
+LCP2_HD u64 gl_add_nc(u64 a, u64 b) {
+  u64 s = a + b;
+  return s < a ? s + GL_EPS : s;
+}
+
 LCP2_HD u64 gl_mul(u64 a, u64 b) {
   u64 lo, hi;
   gl_mul_wide(a, b, lo, hi);

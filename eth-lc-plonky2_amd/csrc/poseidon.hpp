@@ -6,10 +6,8 @@
 // `PoseidonGoldilocksConfig`, eth-lc-plonky2/src/main.rs:75).
 //
 // The state lives in 24 VGPRs of one lane; round constants are wave-uniform
-// (scalar loads from the constant segment).  The MDS layer uses the fact that
-// every matrix entry is < 64: the state is split into 32-bit halves, each half
-// is accumulated in 64 bits (v_mad_u64_u32) and the two partial sums are folded
-// with a single Goldilocks reduction per output lane.
+// (scalar loads).  Values stay "lazy" (any u64 congruent to the element) through
+// the 30 rounds and are canonicalised once at the end.
 #pragma once
 #include "gl64.hpp"
 
@@ -21,41 +19,23 @@ constexpr int POS_FULL_HALF = 4;
 constexpr int POS_PARTIAL = 22;
 constexpr int POS_ROUNDS = 30;
 
+// x^7 on lazy (non-canonical) values: two squarings + two products, no canonicalisation in between
 LCP2_HD u64 pos_sbox(u64 x) {
-  u64 x2 = gl_sqr(x);
-  u64 x4 = gl_sqr(x2);
-  u64 x3 = gl_mul(x, x2);
-  return gl_mul(x3, x4);
+  u64 x2 = gl_sqr_nc(x);
+  u64 x4 = gl_sqr_nc(x2);
+  u64 x3 = gl_mul_nc(x, x2);
+  return gl_mul_nc(x3, x4);
 }
 
-// fold lo + hi * 2^32 (lo, hi < 2^42) into one canonical field element
-LCP2_HD u64 pos_fold(u64 lo, u64 hi) {
-  u64 hi_hi = hi >> 32;          // < 2^10
-  u64 hi_lo = hi & GL_EPS;
-  u64 t = lo + ((hi_hi << 32) - hi_hi);  // + hi_hi * (2^64 mod p), no overflow
-  u64 u = hi_lo << 32;
-  u64 r = t + u;
-  if (r < t) r += GL_EPS;
-  return gl_canon(r);
-}
-
-#define LCP2_MDS_C0 17
-#define LCP2_MDS_C1 15
-#define LCP2_MDS_C2 41
-#define LCP2_MDS_C3 16
-#define LCP2_MDS_C4 2
-#define LCP2_MDS_C5 28
-#define LCP2_MDS_C6 13
-#define LCP2_MDS_C7 13
-#define LCP2_MDS_C8 39
-#define LCP2_MDS_C9 18
-#define LCP2_MDS_C10 34
-#define LCP2_MDS_C11 20
-
-// out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  DIAG = [8, 0, ...]
+// MDS layer: out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  CIRC = [17 15 41 16 2 28 13 13 39 18 34 20],
+// DIAG = [8, 0, ...].  On gfx950 every VOP3 integer instruction issues in ~4.4 cycles, v_mad_u64_u32 included
+// (tools/ubench/int_rates.hip), so the cheapest form is the one with the fewest instructions: the state is split
+// into 32-bit halves, each half is accumulated in 64 bits with one v_mad_u64_u32 per product (sums < 2^41) and
+// the two sums are folded with one reduction per lane.  (A 22/21/21-bit limb variant built on 24-bit multiplies
+// was measured 1.4x SLOWER: 24-bit multiplies are not cheaper here and it needs 1.5x the instructions.)
+// Result is lazy (any u64 congruent to the element).
 LCP2_HD void pos_mds(u64 s[12]) {
-  const u32 C[12] = {LCP2_MDS_C0, LCP2_MDS_C1, LCP2_MDS_C2, LCP2_MDS_C3, LCP2_MDS_C4, LCP2_MDS_C5,
-                     LCP2_MDS_C6, LCP2_MDS_C7, LCP2_MDS_C8, LCP2_MDS_C9, LCP2_MDS_C10, LCP2_MDS_C11};
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
@@ -68,32 +48,39 @@ LCP2_HD void pos_mds(u64 s[12]) {
       ah += (u64)hi[(i + r) % 12] * C[i];
     }
     if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-    s[r] = pos_fold(al, ah);
+    // al + ah * 2^32 with al, ah < 2^42:  = al + (ah_hi * 2^64) + (ah_lo << 32),  2^64 = 2^32 - 1 (mod p)
+    u64 ah_hi = ah >> 32;
+    u64 t = al + ((ah_hi << 32) - ah_hi);  // < 2^43
+    u64 u = ah << 32;                      // (ah_lo << 32): the high half of ah is shifted out
+    u64 v = t + u;
+    s[r] = v < t ? v + GL_EPS : v;
   }
 }
 
-// rc: 30 * 12 round constants, canonical.  s: canonical in, canonical out.
+// rc: 30 * 12 round constants, canonical.  s: any u64 values in, canonical out.
 LCP2_HD void pos_permute(u64 s[12], const u64 *__restrict__ rc) {
   int round = 0;
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add(s[i], rc[round * 12 + i]));
+    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add_nc(s[i], rc[round * 12 + i]));
     pos_mds(s);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_PARTIAL; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], rc[round * 12 + i]);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_nc(s[i], rc[round * 12 + i]);
     s[0] = pos_sbox(s[0]);
     pos_mds(s);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add(s[i], rc[round * 12 + i]));
+    for (int i = 0; i < 12; i++) s[i] = pos_sbox(gl_add_nc(s[i], rc[round * 12 + i]));
     pos_mds(s);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
 // ---- round-constant derivation (host side; uploaded to the device once) ----
