@@ -57,8 +57,9 @@ LCP2_HD void pos_mds(u64 s[12]) {
   }
 }
 
+// Portable form (host: challenger, verifier, CPU emulation of the kernels).
 // rc: 30 * 12 round constants, canonical.  s: any u64 values in, canonical out.
-LCP2_HD void pos_permute(u64 s[12], const u64 *__restrict__ rc) {
+LCP2_HD void pos_permute_portable(u64 s[12], const u64 *__restrict__ rc) {
   int round = 0;
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
@@ -81,6 +82,135 @@ LCP2_HD void pos_permute(u64 s[12], const u64 *__restrict__ rc) {
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---------------------------------------------------------------------------------------------------------
+// gfx950 form.  Measured (tools/ubench): VOP3 integer ops ~4.4 cycles per wave-instruction, VOP2 (add/sub with
+// carry through vcc, cndmask) ~2.7, and v_mad_u64_u32 is a VOP3 op like any other.  So the state is kept as
+// 32-bit halves, products are built from v_mad_u64_u32 and carry chains run through vcc in VOP2 encodings; the
+// compiler's own lowering of a 64x64 multiply + reduction is 27 instructions, this one is 17.  hipcc pads nothing
+// inside an asm string, so the wait states it emits itself for the same pairs on gfx950 (VALU writes vcc ->
+// carry-in reader: 1, -> e64 reader of vcc: 2) are written out as s_nop here.
+// All values are lazy (any u64 congruent to the element); the final state is canonicalised.
+
+// (r1:r0) = (a1:a0) * (b1:b0) mod p
+__device__ __forceinline__ void pos_mul_h(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
+  u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
+  u32 c;
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %1, 0, 1, vcc"
+      : "+v"(m), "=v"(c) : "v"(a1), "v"(b0) : "vcc");
+  const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
+  // 128-bit product = (hi1:hi0:lo1:p0)
+  u32 lo1, hi0, hi1;
+  asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %2, vcc, %7, %8, vcc"
+      : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
+  // t = lo - hi1 ; on borrow t -= 2^32 - 1
+  u32 t0, t1, e;
+  asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
+      "s_nop 0\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "s_nop 0\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1) : "vcc");
+  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
+  u64 t = ((u64)t1 << 32) | t0, r;
+  u32 e2;
+  asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %1, 0, -1, vcc"
+      : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t) : "vcc");
+  u32 q0 = (u32)r, q1 = (u32)(r >> 32);
+  asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %3, vcc"
+      : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
+}
+
+__device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1) {
+  u32 a0, a1, b0, b1, c0, c1;
+  pos_mul_h(x0, x1, x0, x1, a0, a1);  // x^2
+  pos_mul_h(a0, a1, a0, a1, b0, b1);  // x^4
+  pos_mul_h(x0, x1, a0, a1, c0, c1);  // x^3
+  pos_mul_h(c0, c1, b0, b1, x0, x1);  // x^7
+}
+
+// state <- MDS(state) + add[0..12) ; add = the next round's constants (or nullptr): the constants ride in the
+// initial value of the accumulators, so the add-round-constant layer costs nothing.
+__device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 nl[12], nh[12];
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 al = 0, ah = 0;
+    if (add) { const u64 k = add[r]; al = (u32)k; ah = k >> 32; }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      al += (u64)lo[(i + r) % 12] * C[i];
+      ah += (u64)hi[(i + r) % 12] * C[i];
+    }
+    if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
+    // al + ah * 2^32 (al, ah < 2^42):  t = al + ah_hi * (2^64 mod p) ;  v = t + (ah_lo << 32), on carry += 2^32 - 1
+    const u64 t = (u64)(u32)(ah >> 32) * 0xFFFFFFFFu + al;
+    const u32 t0 = (u32)t, t1 = (u32)(t >> 32), ah0 = (u32)ah;
+    u32 e;
+    asm("v_add_co_u32 %1, vcc, %4, %5\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %3, %2\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(nl[r]), "=&v"(nh[r]), "=&v"(e) : "v"(t0), "v"(t1), "v"(ah0) : "vcc");
+  }
+#pragma unroll
+  for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
+}
+
+__device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restrict__ rc) {
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { u64 v = gl_add_nc(s[i], rc[i]); lo[i] = (u32)v; hi[i] = (u32)(v >> 32); }
+  int round = 0;
+#pragma unroll 1
+  for (int r = 0; r < POS_FULL_HALF; r++, round++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+  }
+#pragma unroll 1
+  for (int r = 0; r < POS_PARTIAL; r++, round++) {
+    pos_sbox_h(lo[0], hi[0]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+  }
+#pragma unroll 1
+  for (int r = 0; r < POS_FULL_HALF - 1; r++, round++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+  pos_mds_h(lo, hi, nullptr);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(((u64)hi[i] << 32) | lo[i]);
+}
+#endif
+
+LCP2_HD void pos_permute(u64 s[12], const u64 *__restrict__ rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  pos_permute_gfx950(s, rc);
+#else
+  pos_permute_portable(s, rc);
+#endif
 }
 
 // ---- round-constant derivation (host side; uploaded to the device once) ----

@@ -208,3 +208,17 @@ def test_commit_large_properties(gpu_ctx, oracle):
             acc = (acc * x + a) % P
         assert acc == int(leaves[q, 3])
     o.close()
+
+
+@pytest.mark.parametrize("count", [1, 7, 64, 65, 256])
+def test_poseidon_single_wave_batches(gpu_ctx, oracle, count):
+    # one wave per SIMD is the worst case for VALU hazards in the hand-scheduled carry chains: nothing else issues in between
+    rng = np.random.default_rng(1000 + count)
+    for rep in range(4):
+        s = rand_field(rng, (count, 12), canonical=(rep % 2 == 0))
+        if rep == 3:
+            s[:] = np.uint64(P - 1)  # all carries / borrows taken
+        got = gpu_ctx.poseidon_permute_batch(s)
+        want = np.zeros_like(s)
+        oracle.orc_poseidon_permute_batch(vp(s), vp(want), count)
+        assert (got == want).all()
