@@ -9,3 +9,4 @@ from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Pa
                       MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P)
 from .build import build_native  # noqa: F401
 from . import circuit  # noqa: F401,E402
+from . import batch  # noqa: F401,E402
