@@ -1,0 +1,421 @@
+// CircuitBuilder / PartialWitness / CircuitData of the host circuit layer (see lc_plonky2.hpp).
+//
+// Model: a Target is a variable; gadgets allocate gate rows and BIND wire cells to variables; `connect` merges
+// variables (union-find).  build() turns every class of routed cells into one cycle of the copy-constraint
+// permutation (the sigma polynomials), emits selector / constant columns and the gate programs.  The generators
+// of plonky2 are a list of steps evaluated in creation order (gadgets are built in dependency order, so one
+// forward pass replaces plonky2's worklist); a value set twice with different results is the UnsatisfiedError
+// that makes the reference's #[should_panic] tests panic.
+#include <cstdio>
+#include "host_internal.hpp"
+
+namespace lc {
+
+const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+const uint32_t SHA_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+static inline uint32_t rotr(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+
+// ------------------------------------------------------------------ PartialWitness
+void PartialWitness::set_target(Target t, F value) { entries_.push_back({t.id, value % GOLDILOCKS_P}); }
+void PartialWitness::set_hash256_target(const Hash256Target &t, const uint8_t v[32]) {
+  for (int i = 0; i < 8; i++)
+    set_target(t[i].t, ((uint32_t)v[4 * i] << 24) | ((uint32_t)v[4 * i + 1] << 16) | ((uint32_t)v[4 * i + 2] << 8) | v[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------ CircuitBuilder
+struct CircuitBuilder::Impl {
+  std::unique_ptr<CircuitData::Impl> d{new CircuitData::Impl()};
+  std::map<F, uint32_t> const_vars;
+  int const_row = -1, const_slot = 2;
+  std::map<std::pair<F, F>, std::pair<uint32_t, uint32_t>> arith_open;  // (c0, c1) -> (row, next slot)
+  bool built = false;
+
+  uint32_t new_var() { d->parent.push_back((uint32_t)d->parent.size()); return (uint32_t)d->parent.size() - 1; }
+  uint32_t new_row(uint32_t gate, F c0 = 0, F c1 = 0) {
+    d->gate_of_row.push_back(gate);
+    d->row_consts.push_back({c0, c1});
+    return d->nrows++;
+  }
+  void bind(uint32_t row, uint32_t col, uint32_t var) { d->cells.push_back({row, col, var}); }
+};
+
+CircuitBuilder::CircuitBuilder(const CircuitConfig &config) : impl_(new Impl()) {
+  impl_->d->config = config;
+  impl_->new_row(G_PUBLIC_INPUT);  // row 0 carries the public inputs (PublicInputGate)
+}
+CircuitBuilder::~CircuitBuilder() = default;
+
+Target CircuitBuilder::add_virtual_target() { return Target{impl_->new_var()}; }
+BoolTarget CircuitBuilder::add_virtual_bool_target_safe() { return BoolTarget{add_virtual_target()}; }
+Hash256Target CircuitBuilder::add_virtual_hash256_target() {
+  Hash256Target h;
+  for (auto &l : h) l = U32Target{add_virtual_target()};
+  return h;
+}
+
+Target CircuitBuilder::constant(F v) {
+  v %= GOLDILOCKS_P;
+  auto it = impl_->const_vars.find(v);
+  if (it != impl_->const_vars.end()) return Target{it->second};
+  if (impl_->const_slot == 2) { impl_->const_row = (int)impl_->new_row(G_CONSTANT); impl_->const_slot = 0; }
+  uint32_t var = impl_->new_var();
+  impl_->d->row_consts[impl_->const_row][impl_->const_slot] = v;
+  impl_->bind((uint32_t)impl_->const_row, (uint32_t)impl_->const_slot, var);
+  impl_->const_slot++;
+  Op op; op.kind = Op::CONST; op.out = var; op.c0 = v;
+  impl_->d->ops.push_back(op);
+  impl_->const_vars[v] = var;
+  return Target{var};
+}
+
+static Target arithmetic(CircuitBuilder::Impl *b, F c0, Target x, Target y, F c1, Target z) {
+  auto key = std::make_pair(c0, c1);
+  auto it = b->arith_open.find(key);
+  if (it == b->arith_open.end() || it->second.second == ARITH_OPS) {
+    uint32_t row = b->new_row(G_ARITHMETIC, c0, c1);
+    b->arith_open[key] = {row, 0};
+    it = b->arith_open.find(key);
+  }
+  uint32_t row = it->second.first, k = it->second.second++;
+  uint32_t out = b->new_var();
+  b->bind(row, 4 * k, x.id); b->bind(row, 4 * k + 1, y.id); b->bind(row, 4 * k + 2, z.id); b->bind(row, 4 * k + 3, out);
+  Op op; op.kind = Op::ARITH; op.x = x.id; op.y = y.id; op.z = z.id; op.out = out; op.c0 = c0; op.c1 = c1;
+  b->d->ops.push_back(op);
+  return Target{out};
+}
+Target CircuitBuilder::mul_add(Target a, Target b, Target c) { return arithmetic(impl_.get(), 1, a, b, 1, c); }
+Target CircuitBuilder::mul(Target a, Target b) { return arithmetic(impl_.get(), 1, a, b, 0, zero()); }
+Target CircuitBuilder::add(Target a, Target b) { return arithmetic(impl_.get(), 1, a, one(), 1, b); }
+
+void CircuitBuilder::connect(Target a, Target b) {
+  auto &p = impl_->d->parent;
+  uint32_t ra = impl_->d->find(a.id), rb = impl_->d->find(b.id);
+  if (ra != rb) p[std::max(ra, rb)] = std::min(ra, rb);
+}
+void CircuitBuilder::register_public_input(Target t) {
+  uint32_t i = (uint32_t)impl_->d->public_inputs.size();
+  if (i >= impl_->d->config.num_routed_wires) throw std::runtime_error("too many public inputs for one PublicInputGate");
+  impl_->d->public_inputs.push_back(t.id);
+  impl_->bind(0, i, t.id);
+}
+size_t CircuitBuilder::num_gates() const { return impl_->d->nrows; }
+void CircuitBuilder::print_gate_counts(int) const {
+  std::map<uint32_t, size_t> counts;
+  for (auto g : impl_->d->gate_of_row) counts[g]++;
+  printf("Total gate counts:\n");
+  for (auto &kv : counts) printf("- %zu instances of %s\n", kv.second, gate_name(kv.first));
+}
+
+// two_to_one_sha256(left, right) = SHA-256 of the 64-byte message: data block + constant padding block
+Hash256Target CircuitBuilder::two_to_one_sha256(const Hash256Target &left, const Hash256Target &right) {
+  Impl *b = impl_.get();
+  Op op; op.kind = Op::SHA;
+  for (int i = 0; i < 8; i++) { op.in[i] = left[i].t.id; op.in[8 + i] = right[i].t.id; }
+  uint32_t zero_var = zero().id;
+  uint32_t iv[8];
+  for (int i = 0; i < 8; i++) iv[i] = constant(SHA_IV[i]).id;
+  op.first_row = b->d->nrows;
+  // constant schedule of the padding block
+  uint32_t wpad[64] = {0};
+  wpad[0] = 0x80000000u; wpad[15] = 512;
+  for (int t = 16; t < 64; t++) {
+    uint32_t s0 = rotr(wpad[t - 15], 7) ^ rotr(wpad[t - 15], 18) ^ (wpad[t - 15] >> 3);
+    uint32_t s1 = rotr(wpad[t - 2], 17) ^ rotr(wpad[t - 2], 19) ^ (wpad[t - 2] >> 10);
+    wpad[t] = wpad[t - 16] + s0 + wpad[t - 7] + s1;
+  }
+  std::vector<uint32_t> W(64);
+  for (int i = 0; i < 16; i++) W[i] = op.in[i];
+  // 48 schedule rows
+  for (int t = 16; t < 64; t++) {
+    uint32_t row = b->new_row(G_SHA_SCHED);
+    W[t] = b->new_var();
+    op.internal.push_back(W[t]);
+    b->bind(row, 0, W[t - 2]); b->bind(row, 1, W[t - 7]); b->bind(row, 2, W[t - 15]); b->bind(row, 3, W[t - 16]); b->bind(row, 4, W[t]);
+  }
+  uint32_t state[8];
+  for (int i = 0; i < 8; i++) state[i] = iv[i];
+  uint32_t chain[8];
+  for (int i = 0; i < 8; i++) chain[i] = iv[i];
+  for (int c = 0; c < 2; c++) {
+    for (int t = 0; t < 64; t++) {
+      uint32_t t1 = b->new_var(), a_new = b->new_var(), e_new = b->new_var();
+      op.internal.push_back(t1); op.internal.push_back(a_new); op.internal.push_back(e_new);
+      F kconst = c == 0 ? (F)SHA_K[t] : (F)SHA_K[t] + (F)wpad[t];
+      uint32_t re = b->new_row(G_SHA_ROUND_E, kconst, 0);
+      b->bind(re, 0, state[4]); b->bind(re, 1, state[5]); b->bind(re, 2, state[6]); b->bind(re, 3, state[7]); b->bind(re, 4, state[3]);
+      b->bind(re, 5, c == 0 ? W[t] : zero_var); b->bind(re, 6, e_new); b->bind(re, 7, t1);
+      uint32_t ra = b->new_row(G_SHA_ROUND_A);
+      b->bind(ra, 0, state[0]); b->bind(ra, 1, state[1]); b->bind(ra, 2, state[2]); b->bind(ra, 3, t1); b->bind(ra, 4, a_new);
+      state[7] = state[6]; state[6] = state[5]; state[5] = state[4]; state[4] = e_new;
+      state[3] = state[2]; state[2] = state[1]; state[1] = state[0]; state[0] = a_new;
+    }
+    // chaining value + working state, 8 range-checked additions in 3 rows
+    uint32_t outv[8];
+    uint32_t row = 0;
+    for (int i = 0; i < 8; i++) {
+      if (i % SHA_ADD_OPS == 0) row = b->new_row(G_SHA_ADD);
+      int j = i % SHA_ADD_OPS;
+      outv[i] = b->new_var();
+      op.internal.push_back(outv[i]);
+      b->bind(row, 3 * j, chain[i]); b->bind(row, 3 * j + 1, state[i]); b->bind(row, 3 * j + 2, outv[i]);
+    }
+    for (int i = 0; i < 8; i++) { chain[i] = outv[i]; state[i] = outv[i]; }
+  }
+  Hash256Target out;
+  for (int i = 0; i < 8; i++) { op.out8[i] = chain[i]; out[i] = U32Target{Target{chain[i]}}; }
+  b->d->ops.push_back(op);
+  return out;
+}
+
+// ------------------------------------------------------------------ build()
+std::unique_ptr<CircuitData> CircuitBuilder::build() {
+  Impl *b = impl_.get();
+  if (b->built) throw std::runtime_error("CircuitBuilder::build called twice");
+  b->built = true;
+  std::unique_ptr<CircuitData> data(new CircuitData());
+  CircuitData::Impl *d = b->d.get();
+  const CircuitConfig &cfg = d->config;
+  uint32_t degree_bits = 5;  // room for the cap-height-4 Merkle trees of every FRI layer
+  while ((1u << degree_bits) < d->nrows) degree_bits++;
+  const uint64_t n = 1ull << degree_bits;
+  const uint32_t NR = cfg.num_routed_wires, npi = (uint32_t)d->public_inputs.size();
+  GateSetLayout gs = build_gate_set(npi, cfg.max_quotient_degree_factor + 1);
+  CircuitDescription &D = data->desc_;
+  if (lcp2_params_standard(degree_bits, gs.num_selectors + cfg.num_constants, &D.params) != LCP2_OK) throw std::runtime_error("bad circuit size");
+  D.params.num_wires = cfg.num_wires; D.params.num_routed_wires = NR; D.params.rate_bits = cfg.rate_bits; D.params.cap_height = cfg.cap_height;
+  D.params.num_challenges = cfg.num_challenges; D.params.quotient_degree_factor = cfg.max_quotient_degree_factor;
+  D.params.proof_of_work_bits = cfg.proof_of_work_bits; D.params.num_query_rounds = cfg.num_query_rounds;
+  D.num_selectors = gs.num_selectors; D.gates = gs.gates; D.code = gs.code; D.imm = gs.imm; D.num_public_inputs = npi; D.num_regs = gs.num_regs;
+  const uint32_t NC = D.params.num_constants;
+  D.constants_sigmas.assign((size_t)(NC + NR) * n, 0);
+  // selectors and gate constants
+  for (uint64_t r = 0; r < n; r++) {
+    uint32_t g = r < d->nrows ? d->gate_of_row[r] : (uint32_t)G_NOOP;
+    for (uint32_t s = 0; s < gs.num_selectors; s++)
+      D.constants_sigmas[(size_t)s * n + r] = (gs.groups[s].first <= g && g < gs.groups[s].second) ? g : 0xFFFFFFFFull;
+    if (r < d->nrows)
+      for (uint32_t k = 0; k < cfg.num_constants; k++) D.constants_sigmas[(size_t)(gs.num_selectors + k) * n + r] = d->row_consts[r][k];
+  }
+  // k_is = g^j and the subgroup
+  D.k_is.resize(NR);
+  F acc = 1;
+  for (uint32_t j = 0; j < NR; j++) { D.k_is[j] = acc; acc = f_mul(acc, 7); }
+  std::vector<F> sub(n);
+  F w = f_root_of_unity(degree_bits);
+  sub[0] = 1;
+  for (uint64_t i = 1; i < n; i++) sub[i] = f_mul(sub[i - 1], w);
+  // identity permutation, then one cycle per variable class
+  uint64_t *sig = D.constants_sigmas.data() + (size_t)NC * n;
+  for (uint32_t j = 0; j < NR; j++)
+    for (uint64_t i = 0; i < n; i++) sig[(size_t)j * n + i] = f_mul(D.k_is[j], sub[i]);
+  std::vector<uint8_t> taken((size_t)NR * n, 0);
+  std::map<uint32_t, std::vector<std::pair<uint32_t, uint32_t>>> classes;
+  for (const CellBinding &c : d->cells) {
+    if (c.col >= NR) throw std::runtime_error("a bound cell must be a routed wire");
+    if (taken[(size_t)c.col * n + c.row]++) throw std::runtime_error("wire cell bound twice");
+    classes[d->find(c.var)].push_back({c.row, c.col});
+  }
+  for (auto &kv : classes) {
+    auto &cells = kv.second;
+    for (size_t k = 0; k < cells.size(); k++) {
+      auto &cur = cells[k];
+      auto &nxt = cells[(k + 1) % cells.size()];
+      sig[(size_t)cur.second * n + cur.first] = f_mul(D.k_is[nxt.second], sub[nxt.first]);
+    }
+  }
+  data->impl_ = std::move(b->d);
+  return data;
+}
+
+lcp2_circuit_desc CircuitDescription::c_desc() const {
+  lcp2_circuit_desc d{};
+  d.params = params;
+  d.constants_sigmas = constants_sigmas.data(); d.constants_sigmas_mem = LCP2_MEM_HOST;
+  d.k_is = k_is.data(); d.num_selectors = num_selectors; d.num_gates = (uint32_t)gates.size(); d.gates = gates.data();
+  d.code = code.data(); d.code_words = code.size(); d.imm = imm.data(); d.num_imm = imm.size();
+  d.num_public_inputs = num_public_inputs; d.num_regs = num_regs;
+  return d;
+}
+
+// ------------------------------------------------------------------ witness generation
+namespace {
+struct Values {
+  const CircuitData::Impl *d;
+  std::vector<F> val;
+  std::vector<uint8_t> has;
+  explicit Values(const CircuitData::Impl *dd) : d(dd), val(dd->parent.size(), 0), has(dd->parent.size(), 0) {}
+  void set(uint32_t var, F v, const char *what) {
+    uint32_t r = d->find(var);
+    if (has[r] && val[r] != v)
+      throw UnsatisfiedError(std::string("witness conflict on a connected target (") + what + "): " + std::to_string(val[r]) + " vs " + std::to_string(v));
+    val[r] = v; has[r] = 1;
+  }
+  F get(uint32_t var, const char *what) const {
+    uint32_t r = d->find(var);
+    if (!has[r]) throw UnsatisfiedError(std::string("target has no value: ") + what);
+    return val[r];
+  }
+};
+
+inline void put_bits(std::vector<uint64_t> &wires, uint64_t n, uint32_t row, uint32_t base, uint32_t x) {
+  for (int i = 0; i < 32; i++) wires[(size_t)(base + i) * n + row] = (x >> i) & 1;
+}
+inline uint32_t as_u32(F v, const char *what) {
+  if (v > 0xFFFFFFFFull) throw UnsatisfiedError(std::string("value does not fit a U32Target: ") + what);
+  return (uint32_t)v;
+}
+
+// fills the 310 rows of one two_to_one_sha256 and sets its internal / output variables
+void eval_sha(const Op &op, Values &V, std::vector<uint64_t> &wires, uint64_t n) {
+  auto cell = [&](uint32_t row, uint32_t col) -> uint64_t & { return wires[(size_t)col * n + row]; };
+  uint32_t w[64];
+  for (int i = 0; i < 16; i++) w[i] = as_u32(V.get(op.in[i], "sha256 message word"), "sha256 message word");
+  size_t iv = 0;  // index into op.internal
+  uint32_t row = op.first_row;
+  for (int t = 16; t < 64; t++, row++) {
+    uint32_t w2 = w[t - 2], w15 = w[t - 15];
+    uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3), s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+    uint64_t sum = (uint64_t)s1 + w[t - 7] + s0 + w[t - 16];
+    w[t] = (uint32_t)sum;
+    V.set(op.internal[iv++], w[t], "sha256 schedule word");
+    cell(row, 0) = w2; cell(row, 1) = w[t - 7]; cell(row, 2) = w15; cell(row, 3) = w[t - 16]; cell(row, 4) = w[t];
+    put_bits(wires, n, row, 8, w2); put_bits(wires, n, row, 40, w15);
+    cell(row, 104) = (sum >> 32) & 1; cell(row, 105) = (sum >> 33) & 1;
+  }
+  uint32_t wpad[64] = {0};
+  wpad[0] = 0x80000000u; wpad[15] = 512;
+  for (int t = 16; t < 64; t++) {
+    uint32_t s0 = rotr(wpad[t - 15], 7) ^ rotr(wpad[t - 15], 18) ^ (wpad[t - 15] >> 3);
+    uint32_t s1 = rotr(wpad[t - 2], 17) ^ rotr(wpad[t - 2], 19) ^ (wpad[t - 2] >> 10);
+    wpad[t] = wpad[t - 16] + s0 + wpad[t - 7] + s1;
+  }
+  uint32_t chain[8], st[8];
+  for (int i = 0; i < 8; i++) chain[i] = st[i] = SHA_IV[i];
+  for (int c = 0; c < 2; c++) {
+    for (int t = 0; t < 64; t++) {
+      uint32_t a = st[0], bb = st[1], cc = st[2], dd = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+      uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+      uint64_t kw = c == 0 ? (uint64_t)SHA_K[t] : (uint64_t)SHA_K[t] + wpad[t];
+      uint32_t wv = c == 0 ? w[t] : 0;
+      uint64_t sum1 = (uint64_t)h + S1 + ch + kw + wv;
+      uint32_t t1 = (uint32_t)sum1;
+      uint64_t sume = (uint64_t)dd + t1;
+      uint32_t e_new = (uint32_t)sume;
+      uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & bb) ^ (a & cc) ^ (bb & cc);
+      uint64_t suma = (uint64_t)t1 + S0 + mj;
+      uint32_t a_new = (uint32_t)suma;
+      V.set(op.internal[iv++], t1, "sha256 t1"); V.set(op.internal[iv++], a_new, "sha256 a"); V.set(op.internal[iv++], e_new, "sha256 e");
+      // round E row
+      cell(row, 0) = e; cell(row, 1) = f; cell(row, 2) = g; cell(row, 3) = h; cell(row, 4) = dd; cell(row, 5) = wv; cell(row, 6) = e_new; cell(row, 7) = t1;
+      put_bits(wires, n, row, 8, e); put_bits(wires, n, row, 40, f); put_bits(wires, n, row, 72, g);
+      uint64_t k1 = sum1 >> 32;
+      cell(row, 104) = k1 & 1; cell(row, 105) = (k1 >> 1) & 1; cell(row, 106) = (k1 >> 2) & 1; cell(row, 107) = sume >> 32;
+      row++;
+      // round A row
+      cell(row, 0) = a; cell(row, 1) = bb; cell(row, 2) = cc; cell(row, 3) = t1; cell(row, 4) = a_new;
+      put_bits(wires, n, row, 8, a); put_bits(wires, n, row, 40, bb); put_bits(wires, n, row, 72, cc);
+      uint64_t k2 = suma >> 32;
+      cell(row, 104) = k2 & 1; cell(row, 105) = (k2 >> 1) & 1;
+      row++;
+      st[7] = g; st[6] = f; st[5] = e; st[4] = e_new; st[3] = cc; st[2] = bb; st[1] = a; st[0] = a_new;
+    }
+    for (int i = 0; i < 8; i++) {
+      if (i % SHA_ADD_OPS == 0 && i) row++;
+      int j = i % SHA_ADD_OPS;
+      uint64_t sum = (uint64_t)chain[i] + st[i];
+      uint32_t out = (uint32_t)sum;
+      V.set(op.internal[iv++], out, "sha256 chaining value");
+      cell(row, 3 * j) = chain[i]; cell(row, 3 * j + 1) = st[i]; cell(row, 3 * j + 2) = out;
+      put_bits(wires, n, row, 9 + 33 * j, out);
+      cell(row, 9 + 33 * j + 32) = sum >> 32;
+      chain[i] = out;
+    }
+    row++;
+    for (int i = 0; i < 8; i++) st[i] = chain[i];
+  }
+}
+}  // namespace
+
+void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_t> &wires, std::vector<F> &public_inputs) const {
+  const Impl *d = impl_.get();
+  const uint64_t n = 1ull << desc_.params.degree_bits;
+  wires.assign((size_t)desc_.params.num_wires * n, 0);
+  Values V(d);
+  for (auto &e : pw.entries()) V.set(e.first, e.second, "PartialWitness");
+  // plonky2 runs its generators from a worklist; here the steps are re-scanned until none is left waiting
+  // (gadgets may be wired after they are built: ssz_sync_committee connects the leaves of an existing tree)
+  auto ready = [&](const Op &op) {
+    auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
+    if (op.kind == Op::ARITH) return has(op.x) && has(op.y) && has(op.z);
+    if (op.kind == Op::SHA) { for (uint32_t v : op.in) if (!has(v)) return false; }
+    return true;
+  };
+  std::vector<const Op *> pending;
+  for (const Op &op : d->ops) pending.push_back(&op);
+  while (!pending.empty()) {
+    std::vector<const Op *> waiting;
+    for (const Op *opp : pending) {
+      const Op &op = *opp;
+      if (!ready(op)) { waiting.push_back(opp); continue; }
+      switch (op.kind) {
+        case Op::CONST: V.set(op.out, op.c0, "constant"); break;
+        case Op::ARITH: {
+          F x = V.get(op.x, "arithmetic input"), y = V.get(op.y, "arithmetic input"), z = V.get(op.z, "arithmetic input");
+          V.set(op.out, f_add(f_mul(f_mul(x, y), op.c0), f_mul(z, op.c1)), "arithmetic output");
+          break;
+        }
+        case Op::SHA: eval_sha(op, V, wires, n); break;
+      }
+    }
+    if (waiting.size() == pending.size()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
+    pending.swap(waiting);
+  }
+  for (const CellBinding &c : d->cells) wires[(size_t)c.col * n + c.row] = V.get(c.var, "wire cell");
+  public_inputs.clear();
+  for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
+}
+
+// ------------------------------------------------------------------ prove / verify through the C ABI
+CircuitData::~CircuitData() {
+  if (impl_) {
+    if (impl_->gpu) lcp2_circuit_destroy(impl_->gpu);
+    if (impl_->verifier) lcp2_circuit_destroy(impl_->verifier);
+  }
+}
+
+void CircuitData::attach_gpu(lcp2_ctx *ctx) {
+  lcp2_circuit_desc cd = desc_.c_desc();
+  int rc = lcp2_circuit_create(ctx, &cd, &impl_->gpu);
+  if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_circuit_create: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(ctx) + ")");
+  impl_->ctx = ctx;
+}
+
+ProofWithPublicInputs CircuitData::prove(const PartialWitness &pw) {
+  if (!impl_->gpu) throw std::runtime_error("CircuitData::prove needs attach_gpu(): there is no CPU prover in this library");
+  ProofWithPublicInputs out;
+  std::vector<uint64_t> wires;
+  generate_witness(pw, wires, out.public_inputs);  // throws UnsatisfiedError = plonky2's Err
+  out.proof.assign(lcp2_proof_words(&desc_.params), 0);
+  int rc = lcp2_prove(impl_->gpu, wires.data(), LCP2_MEM_HOST, out.public_inputs.data(), out.proof.data());
+  if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_prove: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(impl_->ctx) + ")");
+  return out;
+}
+
+void CircuitData::verify(const ProofWithPublicInputs &proof) const {
+  const lcp2_circuit *c = impl_->gpu ? impl_->gpu : impl_->verifier;
+  if (!c) throw std::runtime_error("CircuitData::verify needs the circuit digest: attach_gpu() first");
+  int failed = 0;
+  int rc = lcp2_verify(c, proof.proof.data(), proof.public_inputs.data(), &failed);
+  if (rc == LCP2_E_VERIFY) throw VerifyError("proof rejected (check " + std::to_string(failed) + ")");
+  if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_verify: ") + lcp2_status_str(rc));
+}
+
+}  // namespace lc

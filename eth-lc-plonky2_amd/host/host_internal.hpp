@@ -1,0 +1,61 @@
+// Internal declarations of the host circuit layer.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include "lc_plonky2.hpp"
+
+namespace lc {
+
+constexpr int SHA_ADD_OPS = 3;
+constexpr uint32_t ARITH_OPS = 20;
+constexpr uint32_t SHA_ROWS_PER_HASH = 48 + 128 + 3 + 128 + 3;  // 310
+
+struct GateSetLayout {
+  std::vector<std::pair<uint32_t, uint32_t>> groups;
+  uint32_t num_selectors = 0, num_regs = 1;
+  std::vector<lcp2_gate> gates;
+  std::vector<uint32_t> code;
+  std::vector<uint64_t> imm;
+};
+GateSetLayout build_gate_set(uint32_t num_public_inputs, uint32_t max_degree);
+extern const uint32_t GATE_DEGREE[G_COUNT];
+
+// ---- Goldilocks on the host (circuit construction / witness generation only)
+inline F f_add(F a, F b) { F s = a + b; return (s < a || s >= GOLDILOCKS_P) ? s - GOLDILOCKS_P : s; }
+inline F f_mul(F a, F b) { return (F)((unsigned __int128)a * b % GOLDILOCKS_P); }
+inline F f_pow(F b, uint64_t e) { F r = 1; while (e) { if (e & 1) r = f_mul(r, b); b = f_mul(b, b); e >>= 1; } return r; }
+inline F f_root_of_unity(unsigned bits) { return f_pow(f_pow(7, (GOLDILOCKS_P - 1) >> 32), 1ull << (32 - bits)); }
+
+extern const uint32_t SHA_K[64];
+extern const uint32_t SHA_IV[8];
+
+// one generator step, evaluated in creation order by generate_witness
+struct Op {
+  enum Kind { CONST, ARITH, SHA } kind;
+  uint32_t out = 0, x = 0, y = 0, z = 0;  // CONST: out ; ARITH: x, y, z -> out
+  F c0 = 0, c1 = 0;                        // CONST: c0 = value
+  // SHA: message words in[16] -> digest out8[8]; internal words by row
+  std::array<uint32_t, 16> in{};
+  std::array<uint32_t, 8> out8{};
+  uint32_t first_row = 0;
+  std::vector<uint32_t> internal;          // vars: sched W[16..64) (48), then per compression c, per round t: t1, a_new, e_new (2*64*3), then mid[8]
+};
+
+struct CellBinding { uint32_t row, col, var; };
+
+struct CircuitData::Impl {
+  CircuitConfig config;
+  uint32_t nrows = 0;                     // used rows (before padding)
+  std::vector<uint32_t> gate_of_row;
+  std::vector<std::array<F, 2>> row_consts;
+  std::vector<CellBinding> cells;
+  std::vector<uint32_t> parent;           // union-find over variables
+  std::vector<Op> ops;
+  std::vector<uint32_t> public_inputs;    // variables
+  lcp2_ctx *ctx = nullptr;
+  lcp2_circuit *gpu = nullptr;
+  lcp2_circuit *verifier = nullptr;
+  uint32_t find(uint32_t v) const { while (parent[v] != v) v = parent[v]; return v; }
+};
+
+}  // namespace lc

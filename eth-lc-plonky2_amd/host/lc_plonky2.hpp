@@ -1,0 +1,142 @@
+// Host-side mirror of the reference's circuit-building surface, in C++ (the image has no Rust toolchain).
+//
+// Mirrors, name for name, what eth-lc-plonky2 uses from plonky2 / plonky2_crypto and what it defines itself:
+//   CircuitBuilder::{new, add_virtual_target, add_virtual_target_arr, constant, mul_add, connect,
+//                    register_public_input, num_gates, print_gate_counts, build}     (plonky2 plonk/circuit_builder.rs)
+//   CircuitBuilderHash / CircuitBuilderHashSha2::{add_virtual_hash256_target, connect_hash256, two_to_one_sha256},
+//   CircuitBuilderU32::{constant_u32, zero_u32, connect_u32}, WitnessHash::set_hash256_target   (plonky2_crypto)
+//   PartialWitness::{set_target, set_target_arr}, CircuitData::{prove, verify}       (src/main.rs:226-233)
+//   the gadgets of src/merkle_tree_gadget.rs, src/sync_committee_pubkeys.rs and src/targets.rs (gadgets.hpp)
+// Differences that the C ABI forces are documented in DESIGN.md: gates are gate programs, the SHA-256 gate
+// layout is this repository's own (plonky2_crypto's is not visible), public inputs are bound directly.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/lcp2.h"
+
+namespace lc {
+
+using F = uint64_t;  // GoldilocksField, canonical
+constexpr F GOLDILOCKS_P = 0xFFFFFFFF00000001ull;
+
+struct Target { uint32_t id = 0xFFFFFFFFu; };
+struct BoolTarget { Target target; };
+struct U32Target { Target t; };
+using Hash256Target = std::array<U32Target, 8>;
+
+// prove() failed: the witness is inconsistent (plonky2 returns Err; the reference's tests unwrap() -> panic)
+struct UnsatisfiedError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct VerifyError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct CircuitConfig {
+  uint32_t num_wires = 135, num_routed_wires = 80, num_constants = 2, rate_bits = 3, cap_height = 4, num_challenges = 2,
+           max_quotient_degree_factor = 8, proof_of_work_bits = 16, num_query_rounds = 28;
+  static CircuitConfig standard_recursion_config() { return CircuitConfig(); }
+};
+
+// gate kinds of the own layout (sorted by degree then name, as plonky2 sorts its gate set)
+enum GateKind : uint32_t { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_SHA_ADD, G_ARITHMETIC, G_SHA_ROUND_A, G_SHA_ROUND_E, G_SHA_SCHED, G_COUNT };
+const char *gate_name(uint32_t kind);
+
+class PartialWitness {
+ public:
+  void set_target(Target t, F value);
+  template <size_t N> void set_target_arr(const std::array<Target, N> &ts, const std::vector<F> &vals) {
+    for (size_t i = 0; i < N; i++) set_target(ts[i], vals[i]);
+  }
+  void set_u32_target(U32Target t, uint32_t v) { set_target(t.t, v); }
+  void set_hash256_target(const Hash256Target &t, const uint8_t value[32]);  // 8 big-endian u32 limbs
+  void set_bool_target(BoolTarget t, bool v) { set_target(t.target, v ? 1 : 0); }
+  const std::vector<std::pair<uint32_t, F>> &entries() const { return entries_; }
+
+ private:
+  std::vector<std::pair<uint32_t, F>> entries_;
+};
+
+struct ProofWithPublicInputs {
+  std::vector<uint64_t> proof;          // flat layout of include/lcp2.h
+  std::vector<F> public_inputs;
+};
+
+class CircuitData;
+
+class CircuitBuilder {
+ public:
+  explicit CircuitBuilder(const CircuitConfig &config);
+  ~CircuitBuilder();
+  Target add_virtual_target();
+  template <size_t N> std::array<Target, N> add_virtual_target_arr() {
+    std::array<Target, N> a;
+    for (auto &t : a) t = add_virtual_target();
+    return a;
+  }
+  BoolTarget add_virtual_bool_target_safe();
+  Hash256Target add_virtual_hash256_target();
+  Target constant(F v);
+  Target zero() { return constant(0); }
+  Target one() { return constant(1); }
+  U32Target constant_u32(uint32_t v) { return U32Target{constant(v)}; }
+  U32Target zero_u32() { return constant_u32(0); }
+  Target mul_add(Target a, Target b, Target c);  // a * b + c
+  Target mul(Target a, Target b);
+  Target add(Target a, Target b);
+  void connect(Target a, Target b);
+  void connect_u32(U32Target a, U32Target b) { connect(a.t, b.t); }
+  void connect_hash256(const Hash256Target &a, const Hash256Target &b) { for (int i = 0; i < 8; i++) connect(a[i].t, b[i].t); }
+  Hash256Target two_to_one_sha256(const Hash256Target &left, const Hash256Target &right);
+  void register_public_input(Target t);
+  void register_public_inputs(const std::vector<Target> &ts) { for (auto t : ts) register_public_input(t); }
+  size_t num_gates() const;
+  void print_gate_counts(int min_delta) const;
+  // consumes the builder (the reference moves it): selectors, copy-constraint permutation, gate programs
+  std::unique_ptr<CircuitData> build();
+
+  struct Impl;
+  Impl *impl() { return impl_.get(); }
+
+ private:
+  std::unique_ptr<Impl> impl_;
+};
+
+// what build() produced, in the form lcp2_circuit_create consumes (kept by value so tests can hand the same
+// description to another prover, e.g. the CPU oracle)
+struct CircuitDescription {
+  lcp2_params params{};
+  std::vector<uint64_t> constants_sigmas;  // [num_constants + num_routed][n]
+  std::vector<uint64_t> k_is;
+  uint32_t num_selectors = 0;
+  std::vector<lcp2_gate> gates;
+  std::vector<uint32_t> code;
+  std::vector<uint64_t> imm;
+  uint32_t num_public_inputs = 0, num_regs = 1;
+  lcp2_circuit_desc c_desc() const;
+};
+
+class CircuitData {
+ public:
+  ~CircuitData();
+  const CircuitDescription &description() const { return desc_; }
+  uint32_t degree_bits() const { return desc_.params.degree_bits; }
+  uint32_t quotient_degree_factor() const { return desc_.params.quotient_degree_factor; }
+  // generate_partial_witness: runs the generators in creation order, checks every copy constraint and returns the
+  // full wire matrix [num_wires][n] (column-major) and the public inputs; throws UnsatisfiedError on a conflict.
+  void generate_witness(const PartialWitness &pw, std::vector<uint64_t> &wires, std::vector<F> &public_inputs) const;
+  // attaches the MI355X backend: lcp2_circuit_create on `ctx` (commits the preprocessed polynomials)
+  void attach_gpu(lcp2_ctx *ctx);
+  ProofWithPublicInputs prove(const PartialWitness &pw);          // data.prove(pw): needs attach_gpu (no CPU prover here)
+  void verify(const ProofWithPublicInputs &proof) const;          // data.verify(proof): host only
+  struct Impl;
+
+ private:
+  friend class CircuitBuilder;
+  CircuitData() = default;
+  CircuitDescription desc_;
+  std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace lc

@@ -111,9 +111,9 @@ struct orc_circuit {
 };
 #define NPP(p) (((p).num_routed_wires + (p).quotient_degree_factor - 1) / (p).quotient_degree_factor - 1)
 
-orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is, uint32_t num_selectors,
-                             const orc_gate *gates, uint32_t num_gates, const uint32_t *code, size_t code_words,
-                             const uint64_t *imm, size_t num_imm, uint32_t npi) {
+static orc_circuit *circuit_new(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is, uint32_t num_selectors,
+                                const orc_gate *gates, uint32_t num_gates, const uint32_t *code, size_t code_words,
+                                const uint64_t *imm, size_t num_imm, uint32_t npi, int commit) {
   if (p->num_challenges > 4 || p->num_query_rounds > 64 || p->num_fri_layers > ORC_MAX_FRI_LAYERS) return NULL;
   if (p->quotient_degree_factor != (1u << p->rate_bits)) return NULL; /* the LDE doubles as the quotient domain */
   orc_circuit *c = (orc_circuit *)xcalloc(1, sizeof *c);
@@ -125,8 +125,9 @@ orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigm
   c->k_is = (uint64_t *)xmalloc(p->num_routed_wires * 8); for (uint32_t i = 0; i < p->num_routed_wires; i++) c->k_is[i] = gl_canon(k_is[i]);
   c->cs_values = (uint64_t *)xmalloc(ncs * c->n * 8);
   for (size_t i = 0; i < ncs * c->n; i++) c->cs_values[i] = gl_canon(constants_sigmas[i]);
-  c->cs = batch_from_values(c->cs_values, ncs, p->degree_bits, p->rate_bits, p->cap_height);
   for (uint32_t g = 0; g < num_gates; g++) if (gates[g].num_constraints > c->max_gate_constraints) c->max_gate_constraints = gates[g].num_constraints;
+  if (!commit) return c; /* witness checking only: no preprocessed commitment, no digest */
+  c->cs = batch_from_values(c->cs_values, ncs, p->degree_bits, p->rate_bits, p->cap_height);
   /* circuit digest = H(constants_sigmas_cap || degree_bits) */
   size_t capw = (size_t)4 << p->cap_height;
   uint64_t *buf = (uint64_t *)xmalloc((capw + 1) * 8);
@@ -135,6 +136,17 @@ orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigm
   orc_hash_no_pad(buf, capw + 1, c->digest);
   free(buf);
   return c;
+}
+orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is, uint32_t num_selectors,
+                             const orc_gate *gates, uint32_t num_gates, const uint32_t *code, size_t code_words,
+                             const uint64_t *imm, size_t num_imm, uint32_t npi) {
+  return circuit_new(p, constants_sigmas, k_is, num_selectors, gates, num_gates, code, code_words, imm, num_imm, npi, 1);
+}
+/* circuit for orc_check_witness only (skips the constants/sigmas commitment, which dominates at 2^19 rows) */
+orc_circuit *orc_circuit_new_unbuilt(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is, uint32_t num_selectors,
+                                     const orc_gate *gates, uint32_t num_gates, const uint32_t *code, size_t code_words,
+                                     const uint64_t *imm, size_t num_imm, uint32_t npi) {
+  return circuit_new(p, constants_sigmas, k_is, num_selectors, gates, num_gates, code, code_words, imm, num_imm, npi, 0);
 }
 void orc_circuit_free(orc_circuit *c) {
   if (!c) return;

@@ -39,6 +39,9 @@ typedef struct orc_circuit orc_circuit;
 orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is,
                              uint32_t num_selectors, const orc_gate *gates, uint32_t num_gates, const uint32_t *code,
                              size_t code_words, const uint64_t *imm, size_t num_imm, uint32_t num_public_inputs);
+orc_circuit *orc_circuit_new_unbuilt(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is,
+                                     uint32_t num_selectors, const orc_gate *gates, uint32_t num_gates, const uint32_t *code,
+                                     size_t code_words, const uint64_t *imm, size_t num_imm, uint32_t num_public_inputs);
 void orc_circuit_free(orc_circuit *c);
 void orc_circuit_digest(const orc_circuit *c, uint64_t digest[4], uint64_t *cap /* 2^cap_height*4, nullable */);
 size_t orc_proof_words(const orc_params *p);

@@ -1,0 +1,265 @@
+// Circuit-level tests that mirror the reference's own #[test]s one for one (same data, same shape:
+// build gadget -> set witness incl. the EXPECTED output connected to the computed one -> prove -> verify):
+//   src/merkle_tree_gadget.rs:183-325     test_merkle_root_{2,4,8,16}_leaves
+//   src/sync_committee_pubkeys.rs:100-653 test_ssz_sync_committee              (BASELINE configs[1])
+//   src/unit_tests.rs:37-246              test_signing_root, test_beacon_block_header, test_verify_finality_branch,
+//                                         test_contract_state                   (BASELINE configs[0])
+//   src/unit_tests.rs:288-620             sync-committee branch (index 55, height 5): one positive, one #[should_panic]
+// usage: test_gadgets <cpu|gpu> <test name | all>
+//   cpu: witness generation + row-wise constraint check + oracle prove/verify (the oracle is the checker; the product
+//        library has no CPU prover) + the product's host verifier on the oracle's proof
+//   gpu: data.prove(pw) on the MI355X through the C ABI, data.verify(proof), and word-for-word parity with the oracle
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include "../../eth-lc-plonky2_amd/host/gadgets.hpp"
+#include "../../oracle/plonk.h"
+#include "golden_data.hpp"
+
+using namespace lc;
+
+static bool g_gpu = false;
+static lcp2_ctx *g_ctx = nullptr;
+static bool g_skip_oracle_prove = false;  // set by the large test in cpu mode
+
+static std::array<uint8_t, 32> a32(const uint8_t *p) { std::array<uint8_t, 32> a; memcpy(a.data(), p, 32); return a; }
+
+// src/unit_tests.rs:29-35 prove_and_verify
+static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
+  const CircuitDescription &D = data.description();
+  std::vector<uint64_t> wires;
+  std::vector<F> pis;
+  auto t0 = std::chrono::steady_clock::now();
+  data.generate_witness(witness, wires, pis);  // throws UnsatisfiedError = prove() returning Err
+  orc_params op;
+  static_assert(sizeof(orc_params) == sizeof(lcp2_params), "parameter layouts must agree");
+  memcpy(&op, &D.params, sizeof op);
+  std::vector<orc_gate> og(D.gates.size());
+  static_assert(sizeof(orc_gate) == sizeof(lcp2_gate), "gate layouts must agree");
+  memcpy(og.data(), D.gates.data(), og.size() * sizeof(orc_gate));
+  // the oracle's build() (constants/sigmas commitment) is only needed when the oracle proves or verifies
+  const bool need_built = !g_skip_oracle_prove || g_gpu;
+  orc_circuit *oc = (need_built ? orc_circuit_new : orc_circuit_new_unbuilt)(
+      &op, D.constants_sigmas.data(), D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(),
+      D.imm.data(), D.imm.size(), D.num_public_inputs);
+  if (!oc) throw std::runtime_error("oracle rejected the circuit description");
+  uint64_t bad[2] = {0, 0};
+  size_t nbad = orc_check_witness(oc, wires.data(), pis.data(), bad);
+  if (nbad) {
+    orc_circuit_free(oc);
+    throw std::runtime_error("gate constraints violated: " + std::to_string(nbad) + " (first: row " + std::to_string(bad[0]) + " constraint " + std::to_string(bad[1]) + ")");
+  }
+  std::vector<uint64_t> oproof;
+  if (!g_skip_oracle_prove) {
+    oproof.resize(orc_proof_words(&op));
+    orc_prove(oc, wires.data(), pis.data(), oproof.data());
+    if (orc_verify(oc, oproof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the oracle proof");
+  }
+  if (g_gpu) {
+    data.attach_gpu(g_ctx);
+    ProofWithPublicInputs proof = data.prove(witness);
+    auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    printf("proved in %lldms (degree_bits %u)\n", (long long)ms, data.degree_bits());
+    data.verify(proof);  // assert!(data.verify(proof).is_ok())
+    if (!oproof.empty() && proof.proof != oproof) throw std::runtime_error("GPU proof differs from the oracle proof");
+    if (orc_verify(oc, proof.proof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the GPU proof");
+  } else if (oproof.empty()) {
+    printf("witness generated and every gate constraint checked (oracle), degree_bits %u\n", data.degree_bits());
+  } else {
+    // product host verifier on the oracle's proof (verifier-only circuit: digest + cap from the oracle's build)
+    uint64_t digest[4];
+    std::vector<uint64_t> cap((size_t)4 << D.params.cap_height);
+    orc_circuit_digest(oc, digest, cap.data());
+    lcp2_circuit_desc cd = D.c_desc();
+    lcp2_circuit *vc = nullptr;
+    if (lcp2_verifier_create(&cd, digest, cap.data(), &vc) != LCP2_OK) throw std::runtime_error("lcp2_verifier_create failed");
+    int failed = 0;
+    int rc = lcp2_verify(vc, oproof.data(), pis.data(), &failed);
+    lcp2_circuit_destroy(vc);
+    if (rc != LCP2_OK) throw std::runtime_error("product verifier rejected the oracle proof, check " + std::to_string(failed));
+    printf("proved (oracle) and verified, degree_bits %u\n", data.degree_bits());
+  }
+  orc_circuit_free(oc);
+}
+
+// ---- src/merkle_tree_gadget.rs:183-325
+static void merkle_root_zero_leaves(size_t height, const uint8_t *root) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  size_t num_gates = builder.num_gates();
+  MerkleTreeSha256Target merkle_tree_target = add_virtual_merkle_tree_sha256_target(builder, height);
+  Hash256Target expected_root = builder.add_virtual_hash256_target();
+  builder.connect_hash256(merkle_tree_target.root, expected_root);
+  num_gates = builder.num_gates() - num_gates;
+  auto data = builder.build();
+  printf("circuit num_gates=%zu, quotient_degree_factor=%u\n", num_gates, data->quotient_degree_factor());
+  PartialWitness pw;
+  std::vector<std::array<uint8_t, 32>> leaves((size_t)1 << height);
+  for (auto &l : leaves) l.fill(0);
+  set_partial_merkle_tree_sha256_target(pw, leaves, merkle_tree_target);
+  pw.set_hash256_target(expected_root, root);
+  prove_and_verify(*data, pw);
+}
+static void test_merkle_root_2_leaves() { merkle_root_zero_leaves(1, ZERO_ROOT_2); }
+static void test_merkle_root_4_leaves() { merkle_root_zero_leaves(2, ZERO_ROOT_4); }
+static void test_merkle_root_8_leaves() { merkle_root_zero_leaves(3, ZERO_ROOT_8); }
+static void test_merkle_root_16_leaves() { merkle_root_zero_leaves(4, ZERO_ROOT_16); }
+static void test_merkle_root_wrong_root_panics() {  // a wrong expected value makes prove() fail (KAT semantics)
+  uint8_t wrong[32];
+  memcpy(wrong, ZERO_ROOT_4, 32);
+  wrong[5] ^= 1;
+  merkle_root_zero_leaves(2, wrong);
+}
+
+// ---- src/sync_committee_pubkeys.rs:100-653
+static void test_ssz_sync_committee() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  std::vector<std::array<Target, G1_PUBKEY_SIZE>> pubkeys_target;
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) pubkeys_target.push_back(builder.add_virtual_target_arr<G1_PUBKEY_SIZE>());
+  auto agg_pk_target = builder.add_virtual_target_arr<G1_PUBKEY_SIZE>();
+  SyncCommitteeTarget sync_committee_target{pubkeys_target, agg_pk_target};
+  Hash256Target sync_committee_ssz_target = ssz_sync_committee(builder, sync_committee_target);
+  builder.print_gate_counts(0);
+  auto data = builder.build();
+  PartialWitness pw;
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) {
+    std::vector<F> pk_bytes_f(SC_PUBKEYS[i], SC_PUBKEYS[i] + G1_PUBKEY_SIZE);
+    pw.set_target_arr(sync_committee_target.pubkeys[i], pk_bytes_f);
+  }
+  std::vector<F> agg_pk_bytes_f(SC_AGG_PUBKEY, SC_AGG_PUBKEY + G1_PUBKEY_SIZE);
+  pw.set_target_arr(sync_committee_target.aggregate_pubkey, agg_pk_bytes_f);
+  pw.set_hash256_target(sync_committee_ssz_target, SC_SSZ_ROOT);
+  g_skip_oracle_prove = true;  // 2^19 rows: the oracle checks every constraint row-wise; proving is left to the GPU run
+  prove_and_verify(*data, pw);
+  g_skip_oracle_prove = false;
+}
+
+// ---- src/unit_tests.rs:37-65
+static void test_signing_root() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  SigningRootTarget t = add_virtual_signing_root_target(builder);
+  PartialWitness witness;
+  witness.set_hash256_target(t.header_root, SIGNING_ROOT__ATTESTED_HEADER_ROOT);
+  witness.set_hash256_target(t.domain, SIGNING_ROOT__DOMAIN);
+  witness.set_hash256_target(t.signing_root, SIGNING_ROOT__SIGNING_ROOT);
+  auto data = builder.build();
+  prove_and_verify(*data, witness);
+}
+// ---- src/unit_tests.rs:67-106
+static void test_beacon_block_header() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  BeaconBlockHeaderTarget t = add_virtual_beacon_block_header_target(builder);
+  PartialWitness witness;
+  set_beacon_block_header_target(witness, BEACON_BLOCK_HEADER__HEADER_ROOT, BEACON_BLOCK_HEADER__SLOT, BEACON_BLOCK_HEADER__PROPOSER_INDEX,
+                                 BEACON_BLOCK_HEADER__PARENT_ROOT, BEACON_BLOCK_HEADER__STATE_ROOT, BEACON_BLOCK_HEADER__BODY_ROOT, t);
+  auto data = builder.build();
+  prove_and_verify(*data, witness);
+}
+// ---- src/unit_tests.rs:108-167
+static void test_verify_finality_branch() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  VerifyMerkleProofTarget t = add_verify_merkle_proof_target(builder, FINALIZED_HEADER_INDEX, FINALIZED_HEADER_HEIGHT);
+  std::vector<std::array<uint8_t, 32>> branch;
+  for (size_t i = 0; i < FINALIZED_HEADER_HEIGHT; i++) branch.push_back(a32(VERIFY_FINALITY_BRANCH__FINALITY_BRANCH[i]));
+  PartialWitness witness;
+  set_verify_merkle_proof_target(witness, VERIFY_FINALITY_BRANCH__FINALIZED_HEADER_ROOT, branch, VERIFY_FINALITY_BRANCH__ATTESTED_STATE_ROOT, t);
+  auto data = builder.build();
+  prove_and_verify(*data, witness);
+}
+// ---- src/unit_tests.rs:169-246  (BASELINE configs[0])
+static void test_contract_state() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  ContractStateTarget t = add_virtual_contract_state_target(builder);
+  PartialWitness witness;
+  uint8_t cur_slot_bytes[32] = {0}, new_slot_bytes[32] = {0};
+  for (int i = 0; i < 8; i++) { cur_slot_bytes[i] = (uint8_t)(CONTRACT_STATE__CUR_SLOT >> (8 * i)); new_slot_bytes[i] = (uint8_t)(CONTRACT_STATE__NEW_SLOT >> (8 * i)); }
+  witness.set_hash256_target(t.cur_state, CONTRACT_STATE__CUR_STATE);
+  witness.set_hash256_target(t.cur_header, CONTRACT_STATE__CUR_HEADER);
+  witness.set_hash256_target(t.cur_slot, cur_slot_bytes);
+  witness.set_hash256_target(t.cur_sync_committee_i, CONTRACT_STATE__CUR_SYNC_COMMITTEE_I);
+  witness.set_hash256_target(t.cur_sync_committee_ii, CONTRACT_STATE__CUR_SYNC_COMMITTEE_II);
+  witness.set_hash256_target(t.new_state, CONTRACT_STATE__NEW_STATE);
+  witness.set_hash256_target(t.new_header, CONTRACT_STATE__NEW_HEADER);
+  witness.set_hash256_target(t.new_slot, new_slot_bytes);
+  witness.set_hash256_target(t.new_sync_committee_i, CONTRACT_STATE__NEW_SYNC_COMMITTEE_I);
+  witness.set_hash256_target(t.new_sync_committee_ii, CONTRACT_STATE__NEW_SYNC_COMMITTEE_II);
+  auto data = builder.build();
+  prove_and_verify(*data, witness);
+}
+// ---- the Merkle-branch part of src/unit_tests.rs:288-383 (positive) and :377-477 (#[should_panic])
+static void sync_committee_branch(const uint8_t *leaf, const uint8_t branch[][32], const uint8_t *root) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  VerifyMerkleProofTarget t = add_verify_merkle_proof_target(builder, SYNC_COMMITTEE_INDEX, SYNC_COMMITTEE_HEIGHT);
+  std::vector<std::array<uint8_t, 32>> br;
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) br.push_back(a32(branch[i]));
+  PartialWitness witness;
+  set_verify_merkle_proof_target(witness, leaf, br, root, t);
+  auto data = builder.build();
+  prove_and_verify(*data, witness);
+}
+static void test_verify_sync_committee_branch() {
+  sync_committee_branch(SC_ATTESTED_FROM_NEXT_PERIOD1__NEW_SYNC_COMMITTEE_II, SC_ATTESTED_FROM_NEXT_PERIOD1__NEW_SYNC_COMMITTEE_II_BRANCH,
+                        SC_ATTESTED_FROM_NEXT_PERIOD1__FINALIZED_STATE_ROOT);
+}
+static void test_verify_sync_committee_branch_panics() {
+  sync_committee_branch(SC_ATTESTED_FROM_NEXT_PERIOD2__NEW_SYNC_COMMITTEE_II, SC_ATTESTED_FROM_NEXT_PERIOD2__NEW_SYNC_COMMITTEE_II_BRANCH,
+                        SC_ATTESTED_FROM_NEXT_PERIOD2__FINALIZED_STATE_ROOT);
+}
+// public inputs + arithmetic glue: read_u32_be of 4 byte targets equals a registered public input
+static void test_read_u32_be_public_input() {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  auto bytes = builder.add_virtual_target_arr<4>();
+  U32Target v = read_u32_be(builder, bytes.data(), 0);
+  builder.register_public_input(v.t);
+  auto data = builder.build();
+  PartialWitness pw;
+  pw.set_target_arr(bytes, {0x12, 0x34, 0x56, 0x78});
+  prove_and_verify(*data, pw);
+  std::vector<uint64_t> wires; std::vector<F> pis;
+  data->generate_witness(pw, wires, pis);
+  if (pis.size() != 1 || pis[0] != 0x12345678ull) throw std::runtime_error("public input value");
+}
+
+struct TestCase { const char *name; std::function<void()> fn; bool should_panic; };
+static const TestCase TESTS[] = {
+    {"test_merkle_root_2_leaves", test_merkle_root_2_leaves, false},
+    {"test_merkle_root_4_leaves", test_merkle_root_4_leaves, false},
+    {"test_merkle_root_8_leaves", test_merkle_root_8_leaves, false},
+    {"test_merkle_root_16_leaves", test_merkle_root_16_leaves, false},
+    {"test_merkle_root_wrong_root_panics", test_merkle_root_wrong_root_panics, true},
+    {"test_signing_root", test_signing_root, false},
+    {"test_beacon_block_header", test_beacon_block_header, false},
+    {"test_verify_finality_branch", test_verify_finality_branch, false},
+    {"test_contract_state", test_contract_state, false},
+    {"test_verify_sync_committee_branch", test_verify_sync_committee_branch, false},
+    {"test_verify_sync_committee_branch_panics", test_verify_sync_committee_branch_panics, true},
+    {"test_read_u32_be_public_input", test_read_u32_be_public_input, false},
+    {"test_ssz_sync_committee", test_ssz_sync_committee, false},
+};
+
+int main(int argc, char **argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s <cpu|gpu> <test|all|list>\n", argv[0]); return 2; }
+  g_gpu = std::string(argv[1]) == "gpu";
+  std::string which = argv[2];
+  if (which == "list") { for (auto &t : TESTS) printf("%s\n", t.name); return 0; }
+  if (g_gpu) {
+    int rc = lcp2_ctx_create(0, nullptr, &g_ctx);
+    if (rc != LCP2_OK) { fprintf(stderr, "lcp2_ctx_create: %s\n", lcp2_status_str(rc)); return 3; }
+  }
+  int failures = 0, ran = 0;
+  for (auto &t : TESTS) {
+    if (which != "all" && which != t.name) continue;
+    ran++;
+    bool panicked = false;
+    std::string msg;
+    try { t.fn(); } catch (const UnsatisfiedError &e) { panicked = true; msg = std::string("UnsatisfiedError: ") + e.what(); }
+    catch (const std::exception &e) { panicked = true; msg = e.what(); if (!t.should_panic) msg = "UNEXPECTED: " + msg; }
+    bool ok = panicked == t.should_panic && (t.should_panic ? msg.rfind("UnsatisfiedError", 0) == 0 : true);
+    printf("test %s ... %s%s%s\n", t.name, ok ? "ok" : "FAILED", msg.empty() ? "" : " -- ", msg.c_str());
+    if (!ok) failures++;
+  }
+  if (g_ctx) lcp2_ctx_destroy(g_ctx);
+  if (!ran) { fprintf(stderr, "no such test\n"); return 2; }
+  return failures ? 1 : 0;
+}

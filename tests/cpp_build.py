@@ -1,0 +1,33 @@
+"""Builds tests/cpp/test_gadgets: the C++ circuit-level tests (host layer + C ABI + oracle as the CPU checker)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+HOST = os.path.join(ROOT, "eth-lc-plonky2_amd", "host")
+BIN = os.path.join(CPP, "test_gadgets")
+
+
+def build():
+    import eth_lc_plonky2_amd as m
+    import oracle_lib
+    m.build_native()
+    oracle_lib.build()
+    hdr = os.path.join(CPP, "golden_data.hpp")
+    gen = os.path.join(CPP, "make_golden_header.py")
+    kat = os.path.join(ROOT, "tests", "golden", "sha256_kat.json")
+    if not os.path.exists(hdr) or os.path.getmtime(hdr) < max(os.path.getmtime(gen), os.path.getmtime(kat)):
+        subprocess.run(["python3", gen, hdr], check=True)
+    srcs = [os.path.join(CPP, "test_gadgets.cpp")] + [os.path.join(HOST, f) for f in ("gates.cpp", "builder.cpp", "gadgets.cpp")]
+    deps = srcs + [hdr] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [
+        os.path.join(ROOT, "include", "lcp2.h"), os.path.join(ROOT, "oracle", "plonk.h")]
+    if not os.path.exists(BIN) or any(os.path.getmtime(d) > os.path.getmtime(BIN) for d in deps):
+        pkg, orc = os.path.join(ROOT, "eth-lc-plonky2_amd"), os.path.join(ROOT, "oracle")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", BIN] + srcs + ["-L", pkg, "-llcp2", "-L", orc, "-loracle",
+                        "-Wl,-rpath," + pkg, "-Wl,-rpath," + orc, "-fopenmp"], check=True)
+    return BIN
+
+
+def run(mode, test, timeout=900):
+    env = dict(os.environ)
+    return subprocess.run([build(), mode, test], capture_output=True, text=True, timeout=timeout, env=env)
