@@ -10,6 +10,7 @@
 //        library has no CPU prover) + the product's host verifier on the oracle's proof
 //   gpu: data.prove(pw) on the MI355X through the C ABI, data.verify(proof), and word-for-word parity with the oracle
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -32,7 +33,25 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
   std::vector<uint64_t> wires;
   std::vector<F> pis;
   auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point a) {
+    return (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - a).count();
+  };
   data.generate_witness(witness, wires, pis);  // throws UnsatisfiedError = prove() returning Err
+  const long long witness_ms = ms_since(t0);
+  if (g_gpu && getenv("LCP2_TIMING_ONLY")) {  // timing run: GPU build + prove + verify only, no oracle work
+    auto t1 = std::chrono::steady_clock::now();
+    data.attach_gpu(g_ctx);
+    const long long build_ms = ms_since(t1);
+    ProofWithPublicInputs warm = data.prove(witness);
+    t1 = std::chrono::steady_clock::now();
+    ProofWithPublicInputs proof = data.prove(witness);
+    const long long prove_ms = ms_since(t1);
+    t1 = std::chrono::steady_clock::now();
+    data.verify(proof);
+    printf("timing: degree_bits %u  generate_witness(host) %lld ms  build(GPU) %lld ms  prove incl. witness (GPU, 2nd call) %lld ms  verify(host) %lld ms\n",
+           data.degree_bits(), witness_ms, build_ms, prove_ms, ms_since(t1));
+    return;
+  }
   orc_params op;
   static_assert(sizeof(orc_params) == sizeof(lcp2_params), "parameter layouts must agree");
   memcpy(&op, &D.params, sizeof op);
