@@ -100,6 +100,12 @@ void launch_gather_rows(hipStream_t s, const u64 *data, u64 col_stride, u32 ncol
 void launch_gather_digests(hipStream_t s, const u64 *digests, const u64 *level_offsets, u32 nsib, const u64 *indices,
                            u32 k, u64 *out);
 
+struct ShaJobDev;
+struct CellDev;
+void launch_sha_jobs_level(hipStream_t s, const ShaJobDev *jobs, u32 first, u32 count, const uint32_t *words_in, uint32_t *rec);
+void launch_sha_fill_rows(hipStream_t s, const ShaJobDev *jobs, u32 njobs, const uint32_t *rec, u64 *wires, u64 n);
+void launch_scatter_cells(hipStream_t s, const CellDev *cells, u64 ncells, u64 *wires, u64 n);
+
 // ---- device-side NTT backend over the launch wrappers ----
 struct DeviceNttBackend {
   lcp2_ctx *ctx;

@@ -4,6 +4,7 @@
 #include "internal.hpp"
 #include "ntt_host.hpp"
 #include "poseidon.hpp"
+#include "sha_layout.hpp"
 
 using namespace lcp2;
 
@@ -456,6 +457,90 @@ extern "C" int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs, uint64_t *lde)
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
   if (coeffs) LCP2_HIP(ctx, hipMemcpyAsync(coeffs, o->coeffs.p, ((size_t)o->ncols << o->log_n) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
   if (lde) LCP2_HIP(ctx, hipMemcpyAsync(lde, o->lde.p, (size_t)o->ncols * o->nleaves() * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
+
+// ------------------------------------------------------------------ K10: witness generation, device buffers
+static_assert(sizeof(lcp2_sha_job) == sizeof(ShaJobDev) && sizeof(lcp2_cell) == sizeof(CellDev), "ABI structs must match the kernels'");
+
+extern "C" int lcp2_sha256_witness(lcp2_ctx *ctx, const lcp2_sha_job *jobs, size_t njobs, const uint32_t *level_start, uint32_t nlevels,
+                                   const uint32_t *words_in, size_t nwords, uint64_t *wires, uint64_t n, uint32_t *digests) {
+  if (!ctx || !wires || (njobs && (!jobs || !level_start || nlevels == 0)) || (nwords && !words_in)) return LCP2_E_INVALID;
+  if (njobs == 0) return LCP2_OK;
+  if (level_start[0] != 0 || level_start[nlevels] != njobs) return ctx->fail(LCP2_E_INVALID, "sha witness: level table does not cover the jobs");
+  // validate once so that the kernels cannot read or write out of range
+  for (uint32_t l = 0; l < nlevels; l++) {
+    if (level_start[l] > level_start[l + 1]) return ctx->fail(LCP2_E_INVALID, "sha witness: level table not monotone");
+    for (uint32_t j = level_start[l]; j < level_start[l + 1]; j++) {
+      if ((uint64_t)jobs[j].first_row + SHA_ROWS > n) return ctx->fail(LCP2_E_INVALID, "sha witness: rows out of range");
+      for (int i = 0; i < 16; i++) {
+        int32_t s = jobs[j].in_src[i];
+        if (s >= 0 ? (size_t)s >= nwords : (uint32_t)((~s) >> 3) >= level_start[l]) return ctx->fail(LCP2_E_INVALID, "sha witness: bad message source");
+      }
+    }
+  }
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d_jobs, d_words, d_rec;
+  LCP2_HIP(ctx, d_jobs.alloc(njobs * sizeof(lcp2_sha_job)));
+  LCP2_HIP(ctx, d_words.alloc(std::max<size_t>(nwords, 1) * 4));
+  LCP2_HIP(ctx, d_rec.alloc(njobs * (size_t)SHA_REC_WORDS * 4));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_jobs.p, jobs, njobs * sizeof(lcp2_sha_job), hipMemcpyHostToDevice, ctx->stream));
+  if (nwords) LCP2_HIP(ctx, hipMemcpyAsync(d_words.p, words_in, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, LCP2_K_SHA256, 96.0 * njobs + 8.0 * 108 * SHA_ROWS * njobs);
+    for (uint32_t l = 0; l < nlevels; l++)
+      launch_sha_jobs_level(ctx->stream, (const ShaJobDev *)d_jobs.p, level_start[l], level_start[l + 1] - level_start[l],
+                            (const uint32_t *)d_words.p, (uint32_t *)d_rec.p);
+    launch_sha_fill_rows(ctx->stream, (const ShaJobDev *)d_jobs.p, (u32)njobs, (const uint32_t *)d_rec.p, (u64 *)wires, n);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+  if (digests) {
+    std::vector<uint32_t> rec(njobs * (size_t)SHA_REC_WORDS);
+    LCP2_HIP(ctx, hipMemcpyAsync(rec.data(), d_rec.p, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t j = 0; j < njobs; j++) memcpy(digests + 8 * j, rec.data() + j * SHA_REC_WORDS + SHA_REC_DIGEST, 32);
+  }
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the temporaries are freed on return
+  return LCP2_OK;
+}
+
+extern "C" int lcp2_scatter_cells(lcp2_ctx *ctx, const lcp2_cell *cells, size_t ncells, uint64_t *wires, uint64_t n) {
+  if (!ctx || !wires || (ncells && !cells)) return LCP2_E_INVALID;
+  if (!ncells) return LCP2_OK;
+  for (size_t i = 0; i < ncells; i++)
+    if (cells[i].row >= n) return ctx->fail(LCP2_E_INVALID, "scatter: row out of range");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  LCP2_HIP(ctx, d.alloc(ncells * sizeof(lcp2_cell)));
+  LCP2_HIP(ctx, hipMemcpyAsync(d.p, cells, ncells * sizeof(lcp2_cell), hipMemcpyHostToDevice, ctx->stream));
+  launch_scatter_cells(ctx->stream, (const CellDev *)d.p, ncells, (u64 *)wires, n);
+  LCP2_HIP(ctx, hipGetLastError());
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
+
+extern "C" int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev) {
+  if (!ctx || !dev) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_HIP(ctx, hipMalloc(dev, bytes ? bytes : 8));
+  return LCP2_OK;
+}
+extern "C" int lcp2_buffer_free(lcp2_ctx *ctx, void *dev) {
+  if (!ctx) return LCP2_E_INVALID;
+  if (!dev) return LCP2_OK;
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LCP2_HIP(ctx, hipFree(dev));
+  return LCP2_OK;
+}
+extern "C" int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes) {
+  if (!ctx || !dev) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipMemsetAsync(dev, 0, bytes, ctx->stream));
+  return LCP2_OK;
+}
+extern "C" int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+  if (!ctx || !host_dst || !dev_src) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LCP2_OK;
 }

@@ -386,6 +386,7 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
 // ------------------------------------------------------------------ prove / verify through the C ABI
 CircuitData::~CircuitData() {
   if (impl_) {
+    if (impl_->d_wires) lcp2_buffer_free(impl_->ctx, impl_->d_wires);
     if (impl_->gpu) lcp2_circuit_destroy(impl_->gpu);
     if (impl_->verifier) lcp2_circuit_destroy(impl_->verifier);
   }
@@ -396,15 +397,116 @@ void CircuitData::attach_gpu(lcp2_ctx *ctx) {
   int rc = lcp2_circuit_create(ctx, &cd, &impl_->gpu);
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_circuit_create: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(ctx) + ")");
   impl_->ctx = ctx;
+  const size_t bytes = (size_t)desc_.params.num_wires * ((size_t)1 << desc_.params.degree_bits) * 8;
+  if (lcp2_buffer_alloc(ctx, bytes, &impl_->d_wires) != LCP2_OK || lcp2_buffer_zero(ctx, impl_->d_wires, bytes) != LCP2_OK)
+    throw std::runtime_error(std::string("witness buffer: ") + lcp2_last_error(ctx));
+}
+
+// generate_partial_witness with the SHA-256 generators on the device.  Host and device alternate until every
+// generator has run: the host evaluates constants / arithmetic from its worklist, then every two_to_one_sha256
+// whose message is known (directly, or as the digest of another hash of the same batch) goes to the GPU as one
+// levelled batch; the digests come back for the copy-constraint conflict check and for generators that use them.
+void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> &public_inputs) {
+  Impl *d = impl_.get();
+  if (!d->gpu) throw std::runtime_error("generate_witness_gpu needs attach_gpu()");
+  const uint64_t n = 1ull << desc_.params.degree_bits;
+  Values V(d);
+  for (auto &e : pw.entries()) V.set(e.first, e.second, "PartialWitness");
+  std::vector<const Op *> host_ops, sha_ops;
+  for (const Op &op : d->ops) (op.kind == Op::SHA ? sha_ops : host_ops).push_back(&op);
+  auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
+  while (true) {
+    bool progress = true;
+    while (progress && !host_ops.empty()) {  // host worklist
+      progress = false;
+      std::vector<const Op *> waiting;
+      for (const Op *op : host_ops) {
+        if (op->kind == Op::ARITH && !(has(op->x) && has(op->y) && has(op->z))) { waiting.push_back(op); continue; }
+        if (op->kind == Op::CONST) V.set(op->out, op->c0, "constant");
+        else V.set(op->out, f_add(f_mul(f_mul(V.get(op->x, "x"), V.get(op->y, "y")), op->c0), f_mul(V.get(op->z, "z"), op->c1)), "arithmetic output");
+        progress = true;
+      }
+      host_ops.swap(waiting);
+    }
+    if (sha_ops.empty()) break;
+    // plan one device batch
+    std::map<uint32_t, uint32_t> produced;  // variable class -> slot * 8 + word
+    std::vector<lcp2_sha_job> jobs;
+    std::vector<uint32_t> level, words;
+    std::vector<const Op *> batch, later;
+    for (const Op *op : sha_ops) {
+      lcp2_sha_job job{};
+      job.first_row = op->first_row;
+      uint32_t lvl = 0;
+      bool ok = true;
+      size_t words_mark = words.size();
+      for (int i = 0; i < 16 && ok; i++) {
+        uint32_t r = d->find(op->in[i]);
+        if (V.has[r]) { job.in_src[i] = (int32_t)words.size(); words.push_back(as_u32(V.val[r], "sha256 message word")); }
+        else {
+          auto it = produced.find(r);
+          if (it == produced.end()) ok = false;
+          else { job.in_src[i] = ~(int32_t)it->second; lvl = std::max(lvl, level[it->second >> 3] + 1); }
+        }
+      }
+      if (!ok) { words.resize(words_mark); later.push_back(op); continue; }
+      uint32_t slot = (uint32_t)jobs.size();
+      for (int w = 0; w < 8; w++) produced[d->find(op->out8[w])] = slot * 8 + w;
+      jobs.push_back(job); level.push_back(lvl); batch.push_back(op);
+    }
+    if (jobs.empty()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
+    // order by level, remap the digest references
+    uint32_t nlev = 0;
+    for (uint32_t l : level) nlev = std::max(nlev, l + 1);
+    std::vector<uint32_t> order(jobs.size()), newslot(jobs.size()), level_start(nlev + 1, 0);
+    for (uint32_t l : level) level_start[l + 1]++;
+    for (uint32_t l = 0; l < nlev; l++) level_start[l + 1] += level_start[l];
+    {
+      std::vector<uint32_t> fill(level_start.begin(), level_start.end() - 1);
+      for (uint32_t s = 0; s < jobs.size(); s++) { newslot[s] = fill[level[s]]++; order[newslot[s]] = s; }
+    }
+    std::vector<lcp2_sha_job> sorted(jobs.size());
+    for (uint32_t s = 0; s < jobs.size(); s++) {
+      lcp2_sha_job j = jobs[s];
+      for (int i = 0; i < 16; i++)
+        if (j.in_src[i] < 0) { uint32_t ref = (uint32_t)~j.in_src[i]; j.in_src[i] = ~(int32_t)(newslot[ref >> 3] * 8 + (ref & 7)); }
+      sorted[newslot[s]] = j;
+    }
+    std::vector<uint32_t> digests(jobs.size() * 8);
+    int rc = lcp2_sha256_witness(d->ctx, sorted.data(), sorted.size(), level_start.data(), nlev, words.data(), words.size(),
+                                 (uint64_t *)d->d_wires, n, digests.data());
+    if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_sha256_witness: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
+    for (uint32_t s = 0; s < batch.size(); s++)
+      for (int w = 0; w < 8; w++) V.set(batch[s]->out8[w], digests[(size_t)newslot[s] * 8 + w], "sha256 digest");
+    sha_ops.swap(later);
+  }
+  if (!host_ops.empty()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
+  // the cells of the non-SHA rows
+  std::vector<lcp2_cell> cells;
+  for (const CellBinding &c : d->cells) {
+    uint32_t g = d->gate_of_row[c.row];
+    if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED) continue;
+    cells.push_back(lcp2_cell{c.row, c.col, V.get(c.var, "wire cell")});
+  }
+  int rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);
+  if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_scatter_cells: ") + lcp2_status_str(rc));
+  public_inputs.clear();
+  for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
+}
+
+void CircuitData::read_device_witness(std::vector<uint64_t> &wires) const {
+  const size_t words = (size_t)desc_.params.num_wires << desc_.params.degree_bits;
+  wires.resize(words);
+  if (!impl_->d_wires || lcp2_buffer_read(impl_->ctx, wires.data(), impl_->d_wires, words * 8) != LCP2_OK)
+    throw std::runtime_error("read_device_witness failed");
 }
 
 ProofWithPublicInputs CircuitData::prove(const PartialWitness &pw) {
   if (!impl_->gpu) throw std::runtime_error("CircuitData::prove needs attach_gpu(): there is no CPU prover in this library");
   ProofWithPublicInputs out;
-  std::vector<uint64_t> wires;
-  generate_witness(pw, wires, out.public_inputs);  // throws UnsatisfiedError = plonky2's Err
+  generate_witness_gpu(pw, out.public_inputs);  // throws UnsatisfiedError = plonky2's Err; the witness stays in HBM
   out.proof.assign(lcp2_proof_words(&desc_.params), 0);
-  int rc = lcp2_prove(impl_->gpu, wires.data(), LCP2_MEM_HOST, out.public_inputs.data(), out.proof.data());
+  int rc = lcp2_prove(impl_->gpu, (const uint64_t *)impl_->d_wires, LCP2_MEM_DEVICE, out.public_inputs.data(), out.proof.data());
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_prove: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(impl_->ctx) + ")");
   return out;
 }

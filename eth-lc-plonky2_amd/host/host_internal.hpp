@@ -53,6 +53,7 @@ struct CircuitData::Impl {
   std::vector<Op> ops;
   std::vector<uint32_t> public_inputs;    // variables
   lcp2_ctx *ctx = nullptr;
+  void *d_wires = nullptr;                // device witness matrix [num_wires][n], zeroed once
   lcp2_circuit *gpu = nullptr;
   lcp2_circuit *verifier = nullptr;
   uint32_t find(uint32_t v) const { while (parent[v] != v) v = parent[v]; return v; }

@@ -129,6 +129,10 @@ class CircuitData {
   // attaches the MI355X backend: lcp2_circuit_create on `ctx` (commits the preprocessed polynomials)
   void attach_gpu(lcp2_ctx *ctx);
   ProofWithPublicInputs prove(const PartialWitness &pw);          // data.prove(pw): needs attach_gpu (no CPU prover here)
+  // the device half of generate_partial_witness: SHA-256 rows are computed and written in HBM (K10), the few
+  // remaining cells are scattered from the host; leaves the witness in the circuit's device buffer
+  void generate_witness_gpu(const PartialWitness &pw, std::vector<F> &public_inputs);
+  void read_device_witness(std::vector<uint64_t> &wires) const;   // test helper: copy of the device witness matrix
   void verify(const ProofWithPublicInputs &proof) const;          // data.verify(proof): host only
   struct Impl;
 

@@ -123,6 +123,33 @@ int lcp2_lde_batch(lcp2_ctx *ctx, const uint64_t *coeffs, uint64_t *out, size_t 
 int lcp2_sha256_tree(lcp2_ctx *ctx, const uint8_t *leaves, uint32_t height, size_t trees,
                      uint8_t *nodes, uint32_t *round_trace, lcp2_mem mem);
 
+/* ------------------------------------------------------------------ SHA-256 witness generation (K10)
+ * Replaces the plonky2_crypto SHA-256 / U32 generators that plonky2's generate_partial_witness runs on one host
+ * thread for every `two_to_one_sha256` (reference call sites src/merkle_tree_gadget.rs:37,57,77,79).  For circuits
+ * laid out with this repository's SHA-256 rows (eth-lc-plonky2_amd/host, csrc/sha_layout.hpp: 310 rows per hash)
+ * the rows are filled directly in the device-resident witness matrix `wires` [num_wires][n] (column-major).
+ * jobs are sorted by dependency level: jobs [level_start[l], level_start[l+1]) only read digests of earlier levels.
+ * in_src[i] >= 0: message word = words_in[in_src[i]] ; in_src[i] < 0: digest word (~in_src[i]) & 7 of job (~in_src[i]) >> 3.
+ * digests (host, njobs * 8 words, nullable) receives every job's digest for the host-side generators that depend on it. */
+typedef struct {
+  uint32_t first_row;
+  int32_t in_src[16];
+} lcp2_sha_job;
+typedef struct {
+  uint32_t row, col;
+  uint64_t value;
+} lcp2_cell;
+int lcp2_sha256_witness(lcp2_ctx *ctx, const lcp2_sha_job *jobs, size_t njobs, const uint32_t *level_start, uint32_t nlevels,
+                        const uint32_t *words_in, size_t nwords, uint64_t *wires, uint64_t n, uint32_t *digests);
+/* wires[col][row] = value for a list of cells (the non-SHA rows: constants, arithmetic glue, public inputs) */
+int lcp2_scatter_cells(lcp2_ctx *ctx, const lcp2_cell *cells, size_t ncells, uint64_t *wires, uint64_t n);
+
+/* device buffers for callers that keep the witness resident in HBM */
+int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev);
+int lcp2_buffer_free(lcp2_ctx *ctx, void *dev);
+int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes);
+int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
 /* ------------------------------------------------------------------ polynomial commitments
  * PolynomialBatch::from_values / from_coeffs (plonky2 fri/oracle.rs): ifft,
  * lde x 2^rate_bits on the coset 7H, leaf hashing, Merkle tree with cap.

@@ -30,4 +30,5 @@ def build():
 
 def run(mode, test, timeout=900):
     env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "16")
     return subprocess.run([build(), mode, test], capture_output=True, text=True, timeout=timeout, env=env)

@@ -30,7 +30,7 @@ def _first_mismatch(m, params, a, b):
     return f"first mismatch at word {pos} of {total} (in or after section {sec}); {bad.size} words differ"
 
 
-@pytest.mark.parametrize("degree_bits", [5, 6, 8, 10, 12, 13, 14])
+@pytest.mark.parametrize("degree_bits", [5, 6, 8, 10, 12, 13])
 def test_proof_equals_oracle(gpu_ctx, oracle, degree_bits):
     import eth_lc_plonky2_amd as m
     params = m.standard_params(degree_bits, 4)
