@@ -36,6 +36,7 @@ constexpr u32 NTT_MAX_L = 13;       // slab = 2^13 elements = 64 KiB of LDS
 constexpr u32 NTT_THREADS = 256;
 constexpr u32 NTT_MAX_STRIDED_B = 9;
 constexpr u32 NTT_SEG_BITS = 4;     // 16 x 8 B = 128-byte runs in strided passes
+constexpr u32 NTT_BATCH = 8;        // elements (butterflies) in flight per thread
 
 struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h]
   const u64 *lo;
@@ -94,19 +95,32 @@ struct NttPass {
     return two_level(p.tw, l * k1);
   }
 
+  // All three phases move NTT_BATCH elements per thread at a time with the loads issued back to back before any
+  // of them is used: with runtime trip counts the compiler otherwise serialises one HBM / LDS round trip per element.
   template <bool INV>
   LCP2_HD void load(u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col, u32 z) const {
     const u64 *src = p.in + (u64)col * p.in_col_stride + (u64)z * p.in_z_stride;
     const u32 n = 1u << p.L;
-    for (u32 i = tid; i < n; i += nthr) {
-      u64 g = global_index(wg, i);
-      u64 v = gl_canon(src[g]);
-      if (!INV) {
-        if (p.scale_mode) v = gl_mul(v, scale_at(g, z));
-      } else {
-        if (p.g_lo) v = gl_mul(v, group_twiddle(wg, i));
+    for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
+      u64 g[NTT_BATCH], v[NTT_BATCH];
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        u32 i = i0 + j * nthr;
+        g[j] = global_index(wg, i < n ? i : 0);  // out-of-range lanes re-read element 0 (always valid)
+        v[j] = src[g[j]];
       }
-      lds[i] = v;
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        u32 i = i0 + j * nthr;
+        if (i >= n) continue;
+        u64 x = gl_canon(v[j]);
+        if (!INV) {
+          if (p.scale_mode) x = gl_mul(x, scale_at(g[j], z));
+        } else {
+          if (p.g_lo) x = gl_mul(x, group_twiddle(wg, i));
+        }
+        lds[i] = x;
+      }
     }
   }
 
@@ -115,19 +129,31 @@ struct NttPass {
   LCP2_HD void stage(u64 *lds, u32 tid, u32 nthr, u32 b) const {
     const u32 half = 1u << (p.L - 1);
     const u32 kb = b - p.S;  // bit position inside the group
-    for (u32 q = tid; q < half; q += nthr) {
-      u32 i0 = ((q >> b) << (b + 1)) | (q & ((1u << b) - 1));
-      u32 i1 = i0 | (1u << b);
-      u32 k = (i0 >> p.S) & ((1u << kb) - 1);
-      u64 w = p.stage_tw[(u64)k << (p.B - 1 - kb)];
-      u64 a = lds[i0], c = lds[i1];
-      if (!INV) {
-        lds[i0] = gl_add(a, c);
-        lds[i1] = gl_mul(gl_sub(a, c), w);
-      } else {
-        u64 t = gl_mul(c, w);
-        lds[i0] = gl_add(a, t);
-        lds[i1] = gl_sub(a, t);
+    for (u32 q0 = tid; q0 < half; q0 += nthr * NTT_BATCH) {
+      u32 i0[NTT_BATCH];
+      u64 a[NTT_BATCH], c[NTT_BATCH], w[NTT_BATCH];
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        u32 q = q0 + j * nthr;
+        if (q >= half) q = 0;
+        i0[j] = ((q >> b) << (b + 1)) | (q & ((1u << b) - 1));
+        u32 k = (i0[j] >> p.S) & ((1u << kb) - 1);
+        w[j] = p.stage_tw[(u64)k << (p.B - 1 - kb)];
+        a[j] = lds[i0[j]];
+        c[j] = lds[i0[j] | (1u << b)];
+      }
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        if (q0 + j * nthr >= half) continue;
+        const u32 i1 = i0[j] | (1u << b);
+        if (!INV) {
+          lds[i0[j]] = gl_add(a[j], c[j]);
+          lds[i1] = gl_mul(gl_sub(a[j], c[j]), w[j]);
+        } else {
+          u64 t = gl_mul(c[j], w[j]);
+          lds[i0[j]] = gl_add(a[j], t);
+          lds[i1] = gl_sub(a[j], t);
+        }
       }
     }
   }
@@ -136,15 +162,27 @@ struct NttPass {
   LCP2_HD void store(const u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col, u32 z) const {
     u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)bitrev32(z, p.zbits) * p.out_z_stride;
     const u32 n = 1u << p.L;
-    for (u32 i = tid; i < n; i += nthr) {
-      u64 g = global_index(wg, i);
-      u64 v = lds[i];
-      if (!INV) {
-        if (p.g_lo) v = gl_mul(v, group_twiddle(wg, i));
-      } else {
-        if (p.scale_mode) v = gl_mul(v, scale_at(g, z));
+    for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
+      u64 v[NTT_BATCH], tw[NTT_BATCH];
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        u32 i = i0 + j * nthr;
+        if (i >= n) i = 0;
+        v[j] = lds[i];
+        tw[j] = 1;
+        if (!INV) {
+          if (p.g_lo) tw[j] = group_twiddle(wg, i);
+        } else {
+          if (p.scale_mode) tw[j] = scale_at(global_index(wg, i), z);
+        }
       }
-      dst[g] = v;
+#pragma unroll
+      for (u32 j = 0; j < NTT_BATCH; j++) {
+        u32 i = i0 + j * nthr;
+        if (i >= n) continue;
+        const bool scaled = INV ? p.scale_mode != 0 : p.g_lo != 0;
+        dst[global_index(wg, i)] = scaled ? gl_mul(v[j], tw[j]) : v[j];
+      }
     }
   }
 };

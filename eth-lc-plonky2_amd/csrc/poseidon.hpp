@@ -94,47 +94,7 @@ LCP2_HD void pos_permute_portable(u64 s[12], const u64 *__restrict__ rc) {
 // carry-in reader: 1, -> e64 reader of vcc: 2) are written out as s_nop here.
 // All values are lazy (any u64 congruent to the element); the final state is canonicalised.
 
-// (r1:r0) = (a1:a0) * (b1:b0) mod p
-__device__ __forceinline__ void pos_mul_h(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
-  u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
-  u32 c;
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %1, 0, 1, vcc"
-      : "+v"(m), "=v"(c) : "v"(a1), "v"(b0) : "vcc");
-  const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
-  // 128-bit product = (hi1:hi0:lo1:p0)
-  u32 lo1, hi0, hi1;
-  asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
-      "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
-      "s_nop 0\n\t"
-      "v_addc_co_u32 %2, vcc, %7, %8, vcc"
-      : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
-  // t = lo - hi1 ; on borrow t -= 2^32 - 1
-  u32 t0, t1, e;
-  asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "s_nop 0\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1) : "vcc");
-  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
-  u64 t = ((u64)t1 << 32) | t0, r;
-  u32 e2;
-  asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %1, 0, -1, vcc"
-      : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t) : "vcc");
-  u32 q0 = (u32)r, q1 = (u32)(r >> 32);
-  asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
-      "s_nop 0\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %3, vcc"
-      : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
-}
+__device__ __forceinline__ void pos_mul_h(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) { gl_mul_halves(a0, a1, b0, b1, r0, r1); }
 
 __device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1) {
   u32 a0, a1, b0, b1, c0, c1;
