@@ -33,10 +33,11 @@
 namespace lcp2 {
 
 constexpr u32 NTT_MAX_L = 13;       // slab = 2^13 elements = 64 KiB of LDS
-constexpr u32 NTT_THREADS = 256;
+constexpr u32 NTT_THREADS = 1024;   // 2 workgroups x 16 waves per CU share the 160 KiB LDS: the stages are barrier/latency bound, so
+                                    // occupancy matters more than work per thread (measured LDE: 256 thr 174 ms, 512 thr 132 ms, 1024 thr 123 ms)
 constexpr u32 NTT_MAX_STRIDED_B = 9;
 constexpr u32 NTT_SEG_BITS = 4;     // 16 x 8 B = 128-byte runs in strided passes
-constexpr u32 NTT_BATCH = 8;        // elements (butterflies) in flight per thread
+constexpr u32 NTT_BATCH = 4;        // elements (butterflies) in flight per thread
 
 struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h]
   const u64 *lo;
