@@ -30,6 +30,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench
+
+
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (counters cannot be read from inside the process):
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, same launch population as the in-process average."""
+    try:
+        k = json.load(open(PMC_TRAFFIC))["kernels"][kernel]
+        return (k["read_GB_per_launch_corrected"] + k["write_GB_per_launch"]) * 1e9
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -150,7 +161,8 @@ def main():
                        "degree_bits": a.degree_bits, "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
                        "parallelism": "replicas x%d (one independent proof per GPU)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": lh["launches"],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves"),
+                         "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
                          "note": "integer-ALU bound (Poseidon): see DESIGN.md; HBM fraction is legitimately low"},
             "kernels": kern,
         }
