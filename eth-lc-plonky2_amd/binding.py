@@ -99,6 +99,7 @@ def load_library():
         "lcp2_buffer_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_commit_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_commit_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
+        "lcp2_commit_cosets": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_oracle_destroy": (None, [c.c_void_p]),
         "lcp2_oracle_open": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]),
         "lcp2_oracle_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
@@ -150,11 +151,12 @@ class Oracle:
         self.ctx, self.handle = ctx, handle
         self.ncols, self.log_n, self.rate_bits, self.cap_height = ncols, log_n, rate_bits, cap_height
         self.cap = cap
+        self.block_first, self.block_count = 0, 1 << rate_bits  # a coset-sharded oracle holds fewer leaf blocks
 
     def open(self, indices):
         idx = _np_u64(indices)
         k = idx.size
-        nsib = self.log_n + self.rate_bits - self.cap_height
+        nsib = self.log_n + self.rate_bits - self.cap_height  # the same for a coset-sharded oracle: local cap = global cap slice
         leaves = np.zeros((k, self.ncols), dtype=np.uint64)
         sib = np.zeros((k, max(nsib, 0), 4), dtype=np.uint64)
         self.ctx._check(self.ctx.lib.lcp2_oracle_open(self.handle, _ptr(idx), k, _ptr(leaves), _ptr(sib)))
@@ -163,7 +165,7 @@ class Oracle:
     def read(self, coeffs=True, lde=True):
         n = 1 << self.log_n
         c = np.zeros((self.ncols, n), dtype=np.uint64) if coeffs else None
-        l = np.zeros((self.ncols, n << self.rate_bits), dtype=np.uint64) if lde else None
+        l = np.zeros((self.ncols, n * self.block_count), dtype=np.uint64) if lde else None
         self.ctx._check(self.ctx.lib.lcp2_oracle_read(self.handle, _ptr(c), _ptr(l)))
         return c, l
 
@@ -266,6 +268,24 @@ class Context:
 
     def commit_coeffs(self, cols, rate_bits=3, cap_height=4, mem=MEM_HOST, shape=None):
         return self._commit(self.lib.lcp2_commit_coeffs, cols, rate_bits, cap_height, mem, shape)
+
+    def commit_cosets(self, coeffs, block_first, block_count, rate_bits=3, cap_height=4, mem=MEM_HOST, shape=None):
+        """One rank's share of a coset-sharded commitment: coefficients of all columns in, its leaf blocks + cap part out."""
+        if mem == MEM_HOST:
+            c = _np_u64(coeffs)
+            ncols, n = c.shape
+            p = _ptr(c)
+        else:
+            ncols, n = shape
+            p = ctypes.c_void_p(coeffs)
+        log_n = int(n).bit_length() - 1
+        cap = np.zeros((block_count << (cap_height - rate_bits), 4), dtype=np.uint64)
+        h = ctypes.c_void_p()
+        self._check(self.lib.lcp2_commit_cosets(self.handle, p, ncols, log_n, rate_bits, cap_height, block_first, block_count, mem,
+                                                ctypes.byref(h), _ptr(cap)))
+        o = Oracle(self, h, ncols, log_n, rate_bits, cap_height, cap)
+        o.block_first, o.block_count = block_first, block_count
+        return o
 
     # ---- timing
     def prof_enable(self, on=True):

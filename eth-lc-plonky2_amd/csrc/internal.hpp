@@ -129,8 +129,15 @@ struct lcp2_oracle {
   lcp2::DevBuf digests;  // level 0 (leaf digests) ... cap level, 4 u64 per node
   std::vector<uint64_t> level_off;  // node offset of each level inside `digests`
   lcp2::DevBuf d_level_off;
-  uint64_t nleaves() const { return (uint64_t)1 << (log_n + rate_bits); }
-  uint32_t nlevels() const { return log_n + rate_bits - cap_height + 1; }
+  // coset-sharded oracle: only the leaf blocks [block_first, block_first + block_count) are held;
+  // block_count = 0 means all 2^rate_bits blocks
+  uint32_t block_first = 0, block_count = 0;
+  uint32_t blocks() const { return block_count ? block_count : (1u << rate_bits); }
+  uint32_t log_blocks() const { uint32_t l = 0; while ((1u << l) < blocks()) l++; return l; }
+  uint64_t nleaves() const { return (uint64_t)blocks() << log_n; }
+  // the local cap: 2^(cap_height - rate_bits) entries per block
+  uint32_t local_cap_height() const { return cap_height - rate_bits + log_blocks(); }
+  uint32_t nlevels() const { return log_n + log_blocks() - local_cap_height() + 1; }
   const lcp2::u64 *cap_dev() const { return digests.u() + 4 * level_off.back(); }
 };
 

@@ -10,7 +10,7 @@ template <bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   NttPass pass{p};
-  const u32 tid = threadIdx.x, wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z;
+  const u32 tid = threadIdx.x, wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z + p.z_base;
   pass.template load<INV>(lds, tid, NTT_THREADS, wg, col, z);
   __syncthreads();
   if (!INV) {

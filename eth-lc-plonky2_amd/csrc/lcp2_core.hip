@@ -235,7 +235,7 @@ static int lde_and_merkle(lcp2_ctx *ctx, lcp2_oracle *o) {
   NttHost<DeviceNttBackend> ntt(be);
   {
     ProfScope ps(ctx, LCP2_K_LDE, (double)o->ncols * (8.0 * n + 8.0 * N));
-    ntt.forward(o->coeffs.u(), n, o->lde.u(), N, o->log_n, o->ncols, GL_GENERATOR, o->rate_bits);
+    ntt.forward(o->coeffs.u(), n, o->lde.u(), N, o->log_n, o->ncols, GL_GENERATOR, o->rate_bits, o->block_first, o->block_count);
   }
   if (be.status) return be.status;
   LCP2_HIP(ctx, hipGetLastError());
@@ -423,6 +423,32 @@ extern "C" int lcp2_commit_coeffs(lcp2_ctx *ctx, const uint64_t *coeffs, size_t 
                                   uint32_t cap_height, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap) {
   return commit_common(ctx, coeffs, ncols, log_n, rate_bits, cap_height, mem, out, cap, false);
 }
+extern "C" int lcp2_commit_cosets(lcp2_ctx *ctx, const uint64_t *coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                  uint32_t cap_height, uint32_t block_first, uint32_t block_count, lcp2_mem mem, lcp2_oracle **out,
+                                  uint64_t *cap_part) {
+  if (!ctx || !coeffs || !out) return LCP2_E_INVALID;
+  *out = nullptr;
+  if (log_n == 0 || log_n + rate_bits > 30 || cap_height < rate_bits || cap_height > log_n + rate_bits)
+    return ctx->fail(LCP2_E_INVALID, "commit_cosets: needs rate_bits <= cap_height <= log_n + rate_bits");
+  if (block_count == 0 || (block_count & (block_count - 1)) || block_first % block_count || block_first + block_count > (1u << rate_bits))
+    return ctx->fail(LCP2_E_INVALID, "commit_cosets: block range must be an aligned power of two");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  Staged si;
+  LCP2_TRY(stage_in(ctx, coeffs, (ncols << log_n) * sizeof(u64), mem, si));
+  lcp2_oracle *o = new lcp2_oracle();
+  o->block_first = block_first; o->block_count = block_count;
+  int rc = commit_coeffs_dev(ctx, si.d, ncols, log_n, rate_bits, cap_height, o, true);
+  const size_t capw = ((size_t)4 << (cap_height - rate_bits)) * block_count;
+  if (rc == LCP2_OK && cap_part) {
+    hipError_t e = hipMemcpyAsync(cap_part, o->cap_dev(), capw * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = ctx->fail(LCP2_E_HIP, "cap copy failed");
+  }
+  if (rc == LCP2_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ctx->fail(LCP2_E_HIP, "sync failed");
+  if (rc != LCP2_OK) { (void)hipStreamSynchronize(ctx->stream); delete o; return rc; }
+  *out = o;
+  return LCP2_OK;
+}
+
 extern "C" void lcp2_oracle_destroy(lcp2_oracle *o) {
   if (!o) return;
   if (o->ctx) { (void)hipSetDevice(o->ctx->device); (void)hipStreamSynchronize(o->ctx->stream); }

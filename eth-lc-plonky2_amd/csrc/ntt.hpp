@@ -51,6 +51,8 @@ struct NttPassParams {
   u64 in_col_stride, out_col_stride;  // elements, per blockIdx.y
   u64 in_z_stride, out_z_stride;      // elements, per blockIdx.z (coset); out uses bitrev(z, zbits)
   u32 zbits;
+  u32 z_base;                         // coset index of blockIdx.z = 0 (coset-sharded LDE: one launch per leaf block)
+  u32 out_block_base;                 // leaf block that sits at offset 0 of `out` (a rank holds blocks [base, base + count))
   u32 L, S, B, g_lo;                  // slab bits, run bits, group bits, bits below the group
   const u64 *stage_tw;                // w_{2^B}^j (or its inverse), j < 2^(B-1)
   TwoLevelTable tw;                   // w_{N_g}^e (or inverse); used when g_lo > 0
@@ -161,7 +163,7 @@ struct NttPass {
 
   template <bool INV>
   LCP2_HD void store(const u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col, u32 z) const {
-    u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)bitrev32(z, p.zbits) * p.out_z_stride;
+    u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)(bitrev32(z, p.zbits) - p.out_block_base) * p.out_z_stride;
     const u32 n = 1u << p.L;
     for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
       u64 v[NTT_BATCH], tw[NTT_BATCH];

@@ -94,7 +94,14 @@ struct NttHost {
   //              coset z (shift * w_{2^(lg+r)}^z) lands in block bitrev(z) of out[col] (2^(lg+r) elements),
   //              i.e. out is the bit-reversed order of the size-2^(lg+r) coset NTT of the zero-padded input.
   // shift = 1 and zbits = 0 gives the plain NTT (no scaling pass).
-  void forward(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols, u64 shift, u32 zbits) {
+  // block_first / block_count (a power of two): only the leaf blocks [block_first, block_first + block_count) are
+  // computed and `out` holds just those, block_first at offset 0 (coset-sharded LDE of SURVEY 8e).
+  void forward(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols, u64 shift, u32 zbits,
+               u32 block_first = 0, u32 block_count = 0) {
+    if (block_count == 0) block_count = 1u << zbits;
+    const bool all_blocks = block_first == 0 && block_count == (1u << zbits);
+    u32 lgcount = 0;
+    while ((1u << lgcount) < block_count) lgcount++;
     NttGroup groups[8];
     int ng = ntt_plan(lg, groups);
     for (int gi = 0; gi < ng; gi++) {
@@ -114,11 +121,19 @@ struct NttHost {
         }
         wgs = 1u << (lg - g.L);
         nz = 1u << zbits;
+        if (!all_blocks) {  // one launch per leaf block: block b holds coset bitrev(b)
+          p.out_block_base = block_first;
+          for (u32 b = block_first; b < block_first + block_count; b++) {
+            p.z_base = bitrev32(b, zbits);
+            be.launch_pass(false, p, wgs, ncols, 1);
+          }
+          continue;
+        }
       } else {
         // remaining groups: in place over the whole out column (all coset blocks are just more sub-transforms)
         p.in = out; p.in_col_stride = out_col_stride;
         p.out = out; p.out_col_stride = out_col_stride;
-        wgs = 1u << (lg + zbits - g.L);
+        wgs = 1u << (lg + lgcount - g.L);
         nz = 1;
       }
       be.launch_pass(false, p, wgs, ncols, nz);

@@ -159,6 +159,16 @@ int lcp2_commit_values(lcp2_ctx *ctx, const uint64_t *cols, size_t ncols, uint32
                        uint32_t cap_height, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap);
 int lcp2_commit_coeffs(lcp2_ctx *ctx, const uint64_t *coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                        uint32_t cap_height, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap);
+/* Coset-sharded commitment for one rank of a multi-GPU proof.  The LDE of size n << rate_bits is
+ * 2^rate_bits coset transforms of size n; in Merkle leaf order coset r is the contiguous LEAF BLOCK bitrev(r), and with
+ * cap_height >= rate_bits every block is 2^(cap_height - rate_bits) whole cap subtrees.  A rank therefore takes the
+ * coefficients of ALL columns (after the all-gather of the column-sharded iNTT outputs), computes only its blocks
+ * [block_first, block_first + block_count) (an aligned power of two), hashes its own leaves and builds its own
+ * subtrees with no cross-GPU hashing; the global cap is the concatenation of the ranks' cap_part arrays in block
+ * order.  cap_part: host, block_count * 2^(cap_height - rate_bits) * 4 elements.  The returned oracle answers
+ * lcp2_oracle_open for LOCAL leaf indices (global leaf index - block_first * n), siblings up to the local cap. */
+int lcp2_commit_cosets(lcp2_ctx *ctx, const uint64_t *coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
+                       uint32_t block_first, uint32_t block_count, lcp2_mem mem, lcp2_oracle **out, uint64_t *cap_part);
 void lcp2_oracle_destroy(lcp2_oracle *o);
 /* MerkleTree::prove + leaf lookup for `k` leaf indices (fri_prover_query_round):
  * leaves [k][ncols], siblings [k][log2(nleaves) - cap_height][4]; host buffers. */

@@ -22,7 +22,7 @@ struct EmuBackend {
     NttPass pass{p};
     std::vector<u64> lds((size_t)1 << p.L);
     const u32 T = NTT_THREADS;
-    for (u32 z = 0; z < nz; z++)
+    for (u32 z = p.z_base; z < p.z_base + nz; z++)
       for (u32 c = 0; c < cols; c++)
         for (u32 w = 0; w < wgs; w++) {
           for (u32 t = 0; t < T; t++) inv ? pass.load<true>(lds.data(), t, T, w, c, z) : pass.load<false>(lds.data(), t, T, w, c, z);
