@@ -54,7 +54,11 @@ CircuitBuilder::CircuitBuilder(const CircuitConfig &config) : impl_(new Impl()) 
 CircuitBuilder::~CircuitBuilder() = default;
 
 Target CircuitBuilder::add_virtual_target() { return Target{impl_->new_var()}; }
-BoolTarget CircuitBuilder::add_virtual_bool_target_safe() { return BoolTarget{add_virtual_target()}; }
+BoolTarget CircuitBuilder::add_virtual_bool_target_safe() {
+  BoolTarget b{add_virtual_target()};
+  assert_bool(b);  // "safe": constrained to {0, 1}
+  return b;
+}
 Hash256Target CircuitBuilder::add_virtual_hash256_target() {
   Hash256Target h;
   for (auto &l : h) l = U32Target{add_virtual_target()};
@@ -94,6 +98,16 @@ static Target arithmetic(CircuitBuilder::Impl *b, F c0, Target x, Target y, F c1
 Target CircuitBuilder::mul_add(Target a, Target b, Target c) { return arithmetic(impl_.get(), 1, a, b, 1, c); }
 Target CircuitBuilder::mul(Target a, Target b) { return arithmetic(impl_.get(), 1, a, b, 0, zero()); }
 Target CircuitBuilder::add(Target a, Target b) { return arithmetic(impl_.get(), 1, a, one(), 1, b); }
+Target CircuitBuilder::sub(Target a, Target b) { return arithmetic(impl_.get(), 1, a, one(), GOLDILOCKS_P - 1, b); }
+Target CircuitBuilder::add_many(const std::vector<Target> &terms) {
+  if (terms.empty()) return zero();
+  Target acc = terms[0];
+  for (size_t i = 1; i < terms.size(); i++) acc = add(acc, terms[i]);
+  return acc;
+}
+BoolTarget CircuitBuilder::not_(BoolTarget b) { return BoolTarget{arithmetic(impl_.get(), GOLDILOCKS_P - 1, b.target, one(), 1, one())}; }
+Target CircuitBuilder::select(BoolTarget b, Target x, Target y) { return mul_add(b.target, sub(x, y), y); }
+void CircuitBuilder::assert_bool(BoolTarget b) { connect(mul(b.target, b.target), b.target); }
 
 void CircuitBuilder::connect(Target a, Target b) {
   auto &p = impl_->d->parent;

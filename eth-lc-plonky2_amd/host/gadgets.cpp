@@ -202,4 +202,181 @@ ContractStateTarget add_virtual_contract_state_target(CircuitBuilder &builder) {
                              new_header, new_slot, new_sync_committee_i, new_sync_committee_ii};
 }
 
+// src/targets.rs:237-302
+VerifySyncCommitteeTarget add_virtual_verify_sync_committe_target(CircuitBuilder &builder) {
+  VerifySyncCommitteeTarget t;
+  t.is_attested_from_next_period = builder.add_virtual_bool_target_safe();
+  t.cur_sync_committee_i = builder.add_virtual_hash256_target();
+  t.cur_sync_committee_ii = builder.add_virtual_hash256_target();
+  t.new_sync_committee_i = builder.add_virtual_hash256_target();
+  t.new_sync_committee_ii = builder.add_virtual_hash256_target();
+  t.finalized_state_root = builder.add_virtual_hash256_target();
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) t.new_sync_committee_ii_branch.push_back(builder.add_virtual_hash256_target());
+  VerifyMerkleProofTarget branch = add_verify_merkle_proof_target(builder, SYNC_COMMITTEE_INDEX, SYNC_COMMITTEE_HEIGHT);
+  builder.connect_hash256(branch.leaf, t.new_sync_committee_ii);
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) builder.connect_hash256(branch.proof[i], t.new_sync_committee_ii_branch[i]);
+  builder.connect_hash256(branch.root, t.finalized_state_root);
+  BoolTarget not_next = builder.not_(t.is_attested_from_next_period);
+  for (int i = 0; i < 8; i++) {  // cur_i == new_i unless attested from the next period
+    Target a = builder.mul(t.cur_sync_committee_i[i].t, not_next.target);
+    Target b = builder.mul(t.new_sync_committee_i[i].t, not_next.target);
+    builder.connect(a, b);
+  }
+  for (int i = 0; i < 8; i++) {  // new_i == cur_ii if attested from the next period
+    Target a = builder.mul(t.cur_sync_committee_ii[i].t, t.is_attested_from_next_period.target);
+    Target b = builder.mul(t.new_sync_committee_i[i].t, t.is_attested_from_next_period.target);
+    builder.connect(a, b);
+  }
+  return t;
+}
+
+// src/targets.rs:184-235 with the BigUint period arithmetic stubbed (see gadgets.hpp)
+FindSyncCommitteeTarget add_virtual_find_sync_committee_target(CircuitBuilder &builder) {
+  FindSyncCommitteeTarget t;
+  t.is_attested_from_next_period = builder.add_virtual_bool_target_safe();
+  t.cur_sync_committee_i = builder.add_virtual_hash256_target();
+  t.cur_sync_committee_ii = builder.add_virtual_hash256_target();
+  for (int i = 0; i < 8; i++)
+    t.sync_committee_for_attested_slot[i] = U32Target{builder.select(t.is_attested_from_next_period, t.cur_sync_committee_ii[i].t, t.cur_sync_committee_i[i].t)};
+  return t;
+}
+
+ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
+  ProofTarget p;
+  p.signing_root_bytes = builder.add_virtual_target_arr<32>();
+  Hash256Target signing_root = builder.add_virtual_hash256_target();
+  for (size_t idx = 0; idx < 8; idx++) builder.connect_u32(read_u32_be(builder, p.signing_root_bytes.data(), idx * 4), signing_root[idx]);
+  p.domain = builder.add_virtual_hash256_target();
+  p.attested_header_root = builder.add_virtual_hash256_target();
+  p.attested_slot = builder.add_virtual_hash256_target();
+  p.attested_proposer_index = builder.add_virtual_hash256_target();
+  p.attested_parent_root = builder.add_virtual_hash256_target();
+  p.attested_state_root = builder.add_virtual_hash256_target();
+  p.attested_body_root = builder.add_virtual_hash256_target();
+  p.finalized_header_root = builder.add_virtual_hash256_target();
+  p.finalized_slot = builder.add_virtual_hash256_target();
+  p.finalized_proposer_index = builder.add_virtual_hash256_target();
+  p.finalized_parent_root = builder.add_virtual_hash256_target();
+  p.finalized_state_root = builder.add_virtual_hash256_target();
+  p.finalized_body_root = builder.add_virtual_hash256_target();
+  for (size_t i = 0; i < FINALIZED_HEADER_HEIGHT; i++) p.finality_branch.push_back(builder.add_virtual_hash256_target());
+  p.cur_state = builder.add_virtual_hash256_target();
+  p.cur_slot = builder.add_virtual_hash256_target();
+  p.cur_header = builder.add_virtual_hash256_target();
+  p.cur_sync_committee_i = builder.add_virtual_hash256_target();
+  p.cur_sync_committee_ii = builder.add_virtual_hash256_target();
+  p.new_state = builder.add_virtual_hash256_target();
+  p.new_sync_committee_i = builder.add_virtual_hash256_target();
+  p.new_sync_committee_ii = builder.add_virtual_hash256_target();
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) p.new_sync_committee_ii_branch.push_back(builder.add_virtual_hash256_target());
+  p.sync_committee = add_virtual_sync_committee_target(builder);
+  Hash256Target sync_committee_ssz = ssz_sync_committee(builder, p.sync_committee);
+  std::vector<Target> bit_targets;
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) { p.sync_committee_bits.push_back(builder.add_virtual_bool_target_safe()); bit_targets.push_back(p.sync_committee_bits.back().target); }
+  p.signature_bytes = builder.add_virtual_target_arr<96>();
+  p.participation = builder.add_many(bit_targets);
+
+  SigningRootTarget signing_root_target = add_virtual_signing_root_target(builder);
+  BeaconBlockHeaderTarget attested = add_virtual_beacon_block_header_target(builder);
+  BeaconBlockHeaderTarget finalized = add_virtual_beacon_block_header_target(builder);
+  VerifyMerkleProofTarget finality_branch_target = add_verify_merkle_proof_target(builder, FINALIZED_HEADER_INDEX, FINALIZED_HEADER_HEIGHT);
+  ContractStateTarget contract_state_target = add_virtual_contract_state_target(builder);
+  FindSyncCommitteeTarget find_sync_committee_target = add_virtual_find_sync_committee_target(builder);
+  VerifySyncCommitteeTarget verify_sync_committe_target = add_virtual_verify_sync_committe_target(builder);
+
+  // *** signing root ***   (the recursive BLS verifier that consumes signing_root_bytes / signature_bytes is stubbed)
+  builder.connect_hash256(signing_root_target.signing_root, signing_root);
+  builder.connect_hash256(signing_root_target.header_root, p.attested_header_root);
+  builder.connect_hash256(signing_root_target.domain, p.domain);
+  // *** attested block header ***
+  builder.connect_hash256(attested.body_root, p.attested_body_root);
+  builder.connect_hash256(attested.header_root, p.attested_header_root);
+  builder.connect_hash256(attested.parent_root, p.attested_parent_root);
+  builder.connect_hash256(attested.proposer_index, p.attested_proposer_index);
+  builder.connect_hash256(attested.slot, p.attested_slot);
+  builder.connect_hash256(attested.state_root, p.attested_state_root);
+  // *** finality branch ***
+  builder.connect_hash256(finality_branch_target.leaf, p.finalized_header_root);
+  builder.connect_hash256(finality_branch_target.root, p.attested_state_root);
+  for (size_t i = 0; i < FINALIZED_HEADER_HEIGHT; i++) builder.connect_hash256(finality_branch_target.proof[i], p.finality_branch[i]);
+  // *** finalized block header ***
+  builder.connect_hash256(finalized.body_root, p.finalized_body_root);
+  builder.connect_hash256(finalized.header_root, p.finalized_header_root);
+  builder.connect_hash256(finalized.parent_root, p.finalized_parent_root);
+  builder.connect_hash256(finalized.proposer_index, p.finalized_proposer_index);
+  builder.connect_hash256(finalized.slot, p.finalized_slot);
+  builder.connect_hash256(finalized.state_root, p.finalized_state_root);
+  // *** sync committee ***
+  builder.connect_hash256(find_sync_committee_target.cur_sync_committee_i, p.cur_sync_committee_i);
+  builder.connect_hash256(find_sync_committee_target.cur_sync_committee_ii, p.cur_sync_committee_ii);
+  builder.connect_hash256(find_sync_committee_target.sync_committee_for_attested_slot, sync_committee_ssz);
+  // *** update sync committee ***
+  builder.connect(find_sync_committee_target.is_attested_from_next_period.target, verify_sync_committe_target.is_attested_from_next_period.target);
+  builder.connect_hash256(verify_sync_committe_target.cur_sync_committee_i, p.cur_sync_committee_i);
+  builder.connect_hash256(verify_sync_committe_target.cur_sync_committee_ii, p.cur_sync_committee_ii);
+  builder.connect_hash256(verify_sync_committe_target.new_sync_committee_i, p.new_sync_committee_i);
+  builder.connect_hash256(verify_sync_committe_target.new_sync_committee_ii, p.new_sync_committee_ii);
+  builder.connect_hash256(verify_sync_committe_target.finalized_state_root, p.attested_state_root);
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) builder.connect_hash256(verify_sync_committe_target.new_sync_committee_ii_branch[i], p.new_sync_committee_ii_branch[i]);
+  p.is_attested_from_next_period = find_sync_committee_target.is_attested_from_next_period;
+  // *** contract state ***
+  builder.connect_hash256(contract_state_target.cur_state, p.cur_state);
+  builder.connect_hash256(contract_state_target.new_state, p.new_state);
+  builder.connect_hash256(contract_state_target.cur_header, p.cur_header);
+  builder.connect_hash256(contract_state_target.cur_slot, p.cur_slot);
+  builder.connect_hash256(contract_state_target.cur_sync_committee_i, p.cur_sync_committee_i);
+  builder.connect_hash256(contract_state_target.cur_sync_committee_ii, p.cur_sync_committee_ii);
+  builder.connect_hash256(contract_state_target.new_header, p.finalized_header_root);
+  builder.connect_hash256(contract_state_target.new_slot, p.finalized_slot);
+  builder.connect_hash256(contract_state_target.new_sync_committee_i, p.new_sync_committee_i);
+  builder.connect_hash256(contract_state_target.new_sync_committee_ii, p.new_sync_committee_ii);
+  return p;
+}
+
+static void u64_le_bytes(uint64_t v, uint8_t out[32]) { for (int i = 0; i < 32; i++) out[i] = i < 8 ? (uint8_t)(v >> (8 * i)) : 0; }
+
+void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], const uint8_t domain[32], uint64_t attested_slot,
+                      uint64_t attested_proposer_index, const uint8_t attested_header_root[32], const uint8_t attested_parent_root[32],
+                      const uint8_t attested_state_root[32], const uint8_t attested_body_root[32], uint64_t finalized_slot,
+                      uint64_t finalized_proposer_index, const uint8_t finalized_header_root[32], const uint8_t finalized_parent_root[32],
+                      const uint8_t finalized_state_root[32], const uint8_t finalized_body_root[32], const uint8_t finality_branch[6][32],
+                      const uint8_t cur_state[32], const uint8_t new_state[32], uint64_t cur_slot, const uint8_t cur_header[32],
+                      const uint8_t cur_sync_committee_i[32], const uint8_t cur_sync_committee_ii[32], const uint8_t new_sync_committee_i[32],
+                      const uint8_t new_sync_committee_ii[32], const std::vector<bool> &sync_committee_bits,
+                      const uint8_t new_sync_committee_ii_branch[5][32], const uint8_t sync_committee_pubkeys[][48],
+                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], bool is_attested_from_next_period,
+                      const ProofTarget &target) {
+  uint8_t tmp[32];
+  witness.set_hash256_target(target.attested_header_root, attested_header_root);
+  witness.set_hash256_target(target.domain, domain);
+  witness.set_target_arr(target.signing_root_bytes, std::vector<F>(signing_root, signing_root + 32));
+  witness.set_hash256_target(target.attested_parent_root, attested_parent_root);
+  witness.set_hash256_target(target.attested_state_root, attested_state_root);
+  witness.set_hash256_target(target.attested_body_root, attested_body_root);
+  u64_le_bytes(attested_slot, tmp); witness.set_hash256_target(target.attested_slot, tmp);
+  u64_le_bytes(attested_proposer_index, tmp); witness.set_hash256_target(target.attested_proposer_index, tmp);
+  witness.set_hash256_target(target.finalized_header_root, finalized_header_root);
+  witness.set_hash256_target(target.finalized_parent_root, finalized_parent_root);
+  witness.set_hash256_target(target.finalized_state_root, finalized_state_root);
+  witness.set_hash256_target(target.finalized_body_root, finalized_body_root);
+  u64_le_bytes(finalized_slot, tmp); witness.set_hash256_target(target.finalized_slot, tmp);
+  u64_le_bytes(finalized_proposer_index, tmp); witness.set_hash256_target(target.finalized_proposer_index, tmp);
+  for (size_t i = 0; i < FINALIZED_HEADER_HEIGHT; i++) witness.set_hash256_target(target.finality_branch[i], finality_branch[i]);
+  u64_le_bytes(cur_slot, tmp); witness.set_hash256_target(target.cur_slot, tmp);
+  witness.set_hash256_target(target.cur_state, cur_state);
+  witness.set_hash256_target(target.cur_header, cur_header);
+  witness.set_hash256_target(target.cur_sync_committee_i, cur_sync_committee_i);
+  witness.set_hash256_target(target.cur_sync_committee_ii, cur_sync_committee_ii);
+  witness.set_hash256_target(target.new_state, new_state);
+  witness.set_hash256_target(target.new_sync_committee_i, new_sync_committee_i);
+  witness.set_hash256_target(target.new_sync_committee_ii, new_sync_committee_ii);
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) witness.set_bool_target(target.sync_committee_bits[i], sync_committee_bits[i]);
+  for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) witness.set_hash256_target(target.new_sync_committee_ii_branch[i], new_sync_committee_ii_branch[i]);
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++)
+    witness.set_target_arr(target.sync_committee.pubkeys[i], std::vector<F>(sync_committee_pubkeys[i], sync_committee_pubkeys[i] + G1_PUBKEY_SIZE));
+  witness.set_target_arr(target.sync_committee.aggregate_pubkey, std::vector<F>(sync_committee_aggregate, sync_committee_aggregate + G1_PUBKEY_SIZE));
+  witness.set_target_arr(target.signature_bytes, std::vector<F>(signature, signature + 96));
+  witness.set_bool_target(target.is_attested_from_next_period, is_attested_from_next_period);
+}
+
 }  // namespace lc

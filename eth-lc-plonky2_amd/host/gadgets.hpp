@@ -29,6 +29,31 @@ struct ContractStateTarget {
       new_sync_committee_i, new_sync_committee_ii;
 };
 
+struct FindSyncCommitteeTarget {
+  BoolTarget is_attested_from_next_period;
+  Hash256Target cur_sync_committee_i, cur_sync_committee_ii, sync_committee_for_attested_slot;
+};
+struct VerifySyncCommitteeTarget {
+  BoolTarget is_attested_from_next_period;
+  Hash256Target cur_sync_committee_i, cur_sync_committee_ii, new_sync_committee_i, new_sync_committee_ii, finalized_state_root;
+  std::vector<Hash256Target> new_sync_committee_ii_branch;
+};
+// src/targets.rs:84-119 ProofTarget without the recursive BLS proof / verifier data and the BigUint slot copies
+struct ProofTarget {
+  std::array<Target, 32> signing_root_bytes;
+  Hash256Target attested_header_root, domain, attested_slot, attested_proposer_index, attested_parent_root, attested_state_root,
+      attested_body_root, finalized_header_root;
+  std::vector<Hash256Target> finality_branch;
+  Hash256Target finalized_slot, finalized_proposer_index, finalized_parent_root, finalized_state_root, finalized_body_root, cur_state,
+      cur_slot, cur_header, cur_sync_committee_i, cur_sync_committee_ii, new_state, new_sync_committee_i, new_sync_committee_ii;
+  std::vector<BoolTarget> sync_committee_bits;
+  std::vector<Hash256Target> new_sync_committee_ii_branch;
+  SyncCommitteeTarget sync_committee;
+  std::array<Target, 96> signature_bytes;
+  BoolTarget is_attested_from_next_period;  // witness of the stubbed period arithmetic (find_sync_committee)
+  Target participation;                      // sum of the sync committee bits (update_validity's threshold is stubbed)
+};
+
 std::vector<Hash256Target> compute_next_layer(CircuitBuilder &builder, size_t layer_size, const std::vector<Hash256Target> &prev_layer);
 MerkleTreeSha256Target add_virtual_merkle_tree_sha256_target(CircuitBuilder &builder, size_t height);
 VerifyMerkleProofTarget add_verify_merkle_proof_target(CircuitBuilder &builder, size_t leaf_index, size_t height);
@@ -48,5 +73,24 @@ void set_beacon_block_header_target(PartialWitness &witness, const uint8_t heade
                                     const uint8_t parent_root[32], const uint8_t state_root[32], const uint8_t body_root[32],
                                     const BeaconBlockHeaderTarget &target);
 ContractStateTarget add_virtual_contract_state_target(CircuitBuilder &builder);
+VerifySyncCommitteeTarget add_virtual_verify_sync_committe_target(CircuitBuilder &builder);
+// STUB: the reference derives is_attested_from_next_period from BigUint slot arithmetic (slot / 8192); here it is a
+// boolean witness and only the committee selection is constrained
+FindSyncCommitteeTarget add_virtual_find_sync_committee_target(CircuitBuilder &builder);
+// src/targets.rs:391-683 with the recursive BLS verifier (:468-482), find_sync_committee's period arithmetic (:184-235),
+// update_validity (:304-332) and the BigUint<->Hash256 slot connections (:646-659) stubbed: BASELINE configs[2]
+ProofTarget add_virtual_proof_target(CircuitBuilder &builder);
+// src/targets.rs:771-898 (same argument order; the BLS proof / verifier data arguments are dropped)
+void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], const uint8_t domain[32], uint64_t attested_slot,
+                      uint64_t attested_proposer_index, const uint8_t attested_header_root[32], const uint8_t attested_parent_root[32],
+                      const uint8_t attested_state_root[32], const uint8_t attested_body_root[32], uint64_t finalized_slot,
+                      uint64_t finalized_proposer_index, const uint8_t finalized_header_root[32], const uint8_t finalized_parent_root[32],
+                      const uint8_t finalized_state_root[32], const uint8_t finalized_body_root[32], const uint8_t finality_branch[6][32],
+                      const uint8_t cur_state[32], const uint8_t new_state[32], uint64_t cur_slot, const uint8_t cur_header[32],
+                      const uint8_t cur_sync_committee_i[32], const uint8_t cur_sync_committee_ii[32], const uint8_t new_sync_committee_i[32],
+                      const uint8_t new_sync_committee_ii[32], const std::vector<bool> &sync_committee_bits,
+                      const uint8_t new_sync_committee_ii_branch[5][32], const uint8_t sync_committee_pubkeys[][48],
+                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], bool is_attested_from_next_period,
+                      const ProofTarget &target);
 
 }  // namespace lc

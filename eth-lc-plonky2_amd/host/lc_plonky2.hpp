@@ -85,6 +85,11 @@ class CircuitBuilder {
   Target mul_add(Target a, Target b, Target c);  // a * b + c
   Target mul(Target a, Target b);
   Target add(Target a, Target b);
+  Target sub(Target a, Target b);
+  Target add_many(const std::vector<Target> &terms);
+  BoolTarget not_(BoolTarget b);                         // builder.not(b) = 1 - b
+  Target select(BoolTarget b, Target x, Target y);       // builder._if / select: b ? x : y
+  void assert_bool(BoolTarget b);                        // b * b = b
   void connect(Target a, Target b);
   void connect_u32(U32Target a, U32Target b) { connect(a.t, b.t); }
   void connect_hash256(const Hash256Target &a, const Hash256Target &b) { for (int i = 0; i < 8; i++) connect(a[i].t, b[i].t); }

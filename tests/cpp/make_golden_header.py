@@ -35,4 +35,21 @@ for test, vals in kat["unit_tests"].items():
             s += arr2(name, v)
         else:
             s += arr(name, v)
+
+# light-client updates 633 -> 634 (src/light_client_updates/*.json, the inputs of src/main.rs:84-175)
+lc = json.load(open(os.path.join(here, "..", "golden", "lc_updates.json")))
+hx = lambda v: bytes.fromhex(v[2:] if v.startswith("0x") else v)
+for tag, u in lc.items():
+    P = "LC%s__" % tag
+    for which, h in (("ATTESTED", u["attested_beacon_header"]), ("FINALIZED", u["finality_update"]["header_update"]["beacon_header"])):
+        s += "static const uint64_t %s%s_SLOT = %dull;\n" % (P, which, int(h["slot"]))
+        s += "static const uint64_t %s%s_PROPOSER_INDEX = %dull;\n" % (P, which, int(h["proposer_index"]))
+        for f in ("parent_root", "state_root", "body_root"):
+            s += arr("%s%s_%s" % (P, which, f.upper()), hx(h[f]))
+    s += arr2(P + "FINALITY_BRANCH", [hx(b) for b in u["finality_update"]["finality_branch"]])
+    s += arr2(P + "NEXT_SYNC_COMMITTEE_PUBKEYS", [hx(b) for b in u["sync_committee_update"]["next_sync_committee"]["pubkeys"]])
+    s += arr(P + "NEXT_SYNC_COMMITTEE_AGGREGATE", hx(u["sync_committee_update"]["next_sync_committee"]["aggregate_pubkey"]))
+    s += arr2(P + "NEXT_SYNC_COMMITTEE_BRANCH", [hx(b) for b in u["sync_committee_update"]["next_sync_committee_branch"]])
+    s += arr(P + "SYNC_COMMITTEE_BITS", hx(u["sync_aggregate"]["sync_committee_bits"]))
+    s += arr(P + "SYNC_COMMITTEE_SIGNATURE", hx(u["sync_aggregate"]["sync_committee_signature"]))
 open(out, "w").write(s)

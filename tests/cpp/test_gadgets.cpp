@@ -4,6 +4,8 @@
 //   src/sync_committee_pubkeys.rs:100-653 test_ssz_sync_committee              (BASELINE configs[1])
 //   src/unit_tests.rs:37-246              test_signing_root, test_beacon_block_header, test_verify_finality_branch,
 //                                         test_contract_state                   (BASELINE configs[0])
+//   src/main.rs:84-233                    test_light_client_update: updates 633 -> 634 through add_virtual_proof_target /
+//                                         set_proof_target (BASELINE configs[2], BLS verifier + BigUint checks stubbed)
 //   src/unit_tests.rs:288-620             sync-committee branch (index 55, height 5): one positive, one #[should_panic]
 // usage: test_gadgets <cpu|gpu> <test name | all>
 //   cpu: witness generation + row-wise constraint check + oracle prove/verify (the oracle is the checker; the product
@@ -250,6 +252,63 @@ static void test_read_u32_be_public_input() {
   if (pis.size() != 1 || pis[0] != 0x12345678ull) throw std::runtime_error("public input value");
 }
 
+// ---- src/main.rs:84-233: the full light-client step for the committed update pair 633 -> 634 (BASELINE configs[2]).
+// Native values (header roots, contract states, committee roots) come from the oracle's SHA-256 restatement, as
+// main.rs takes them from tree_hash_root(); the domain is compute_domain(DOMAIN_SYNC_COMMITTEE, Bellatrix fork
+// version, mainnet genesis_validators_root) -- with the BLS verifier stubbed any 32 bytes keep the circuit consistent.
+static void sha2(const uint8_t *l, const uint8_t *r, uint8_t *out) { orc_sha256_two_to_one(l, r, out); }
+static void light_client_update(bool corrupt_state_root) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  ProofTarget target = add_virtual_proof_target(builder);
+  for (auto &limb : target.cur_state) builder.register_public_input(limb.t);  // src/main.rs:180-187
+  for (auto &limb : target.new_state) builder.register_public_input(limb.t);
+  builder.print_gate_counts(0);
+  auto data = builder.build();
+
+  static const uint8_t DOMAIN[32] = {0x07, 0, 0, 0, 0x4a, 0x26, 0xc5, 0x8b, 0x08, 0xad, 0xd8, 0x08, 0x9b, 0x75, 0xca, 0xa5,
+                                     0x40, 0x84, 0x88, 0x81, 0xa8, 0xd4, 0xf0, 0xaf, 0x0b, 0xe8, 0x34, 0x17, 0xa8, 0x5c, 0x0f, 0x45};
+  uint8_t attested_header_root[32], finalized_header_root[32], cur_header[32], signing_root[32];
+  orc_beacon_header_root(LC634__ATTESTED_SLOT, LC634__ATTESTED_PROPOSER_INDEX, LC634__ATTESTED_PARENT_ROOT, LC634__ATTESTED_STATE_ROOT,
+                         LC634__ATTESTED_BODY_ROOT, attested_header_root);
+  orc_beacon_header_root(LC634__FINALIZED_SLOT, LC634__FINALIZED_PROPOSER_INDEX, LC634__FINALIZED_PARENT_ROOT, LC634__FINALIZED_STATE_ROOT,
+                         LC634__FINALIZED_BODY_ROOT, finalized_header_root);
+  orc_beacon_header_root(LC633__FINALIZED_SLOT, LC633__FINALIZED_PROPOSER_INDEX, LC633__FINALIZED_PARENT_ROOT, LC633__FINALIZED_STATE_ROOT,
+                         LC633__FINALIZED_BODY_ROOT, cur_header);
+  sha2(attested_header_root, DOMAIN, signing_root);
+  // contract state before: slot/header of 633's finalized block, committees (i, ii) = (633's branch[0], root(633.next))
+  uint8_t cur_ii[32], new_ii[32], cur_state[32], new_state[32];
+  orc_ssz_sync_committee_root(&LC633__NEXT_SYNC_COMMITTEE_PUBKEYS[0][0], LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, cur_ii);
+  orc_ssz_sync_committee_root(&LC634__NEXT_SYNC_COMMITTEE_PUBKEYS[0][0], LC634__NEXT_SYNC_COMMITTEE_AGGREGATE, new_ii);
+  const uint8_t *cur_i = LC633__NEXT_SYNC_COMMITTEE_BRANCH[0], *new_i = LC634__NEXT_SYNC_COMMITTEE_BRANCH[0];
+  if (memcmp(cur_ii, new_i, 32) != 0) throw std::runtime_error("fixture: root(633.next_sync_committee) != 634.next_sync_committee_branch[0]");
+  orc_contract_state_root(LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii, cur_state);
+  orc_contract_state_root(LC634__FINALIZED_SLOT, finalized_header_root, new_i, new_ii, new_state);
+  std::vector<bool> bits(SYNC_COMMITTEE_SIZE);
+  size_t participation = 0;
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) { bits[i] = (LC634__SYNC_COMMITTEE_BITS[i / 8] >> (i % 8)) & 1; participation += bits[i]; }
+  const bool next_period = LC634__ATTESTED_SLOT / 8192 == LC633__FINALIZED_SLOT / 8192 + 1;  // find_sync_committee's stubbed arithmetic
+  if (!next_period) throw std::runtime_error("fixture: attested slot is expected to be in the period after the current state");
+  uint8_t attested_state_root[32];
+  memcpy(attested_state_root, LC634__ATTESTED_STATE_ROOT, 32);
+  if (corrupt_state_root) attested_state_root[5] ^= 1;  // breaks the header root, finality branch and committee branch
+
+  PartialWitness pw;
+  set_proof_target(pw, signing_root, DOMAIN, LC634__ATTESTED_SLOT, LC634__ATTESTED_PROPOSER_INDEX, attested_header_root,
+                   LC634__ATTESTED_PARENT_ROOT, attested_state_root, LC634__ATTESTED_BODY_ROOT, LC634__FINALIZED_SLOT,
+                   LC634__FINALIZED_PROPOSER_INDEX, finalized_header_root, LC634__FINALIZED_PARENT_ROOT, LC634__FINALIZED_STATE_ROOT,
+                   LC634__FINALIZED_BODY_ROOT, LC634__FINALITY_BRANCH, cur_state, new_state, LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii,
+                   new_i, new_ii, bits, LC634__NEXT_SYNC_COMMITTEE_BRANCH, LC633__NEXT_SYNC_COMMITTEE_PUBKEYS,
+                   LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC634__SYNC_COMMITTEE_SIGNATURE, next_period, target);
+  printf("light-client update 633 -> 634: participation %zu / 512, attested slot %llu (period %llu), state slot %llu -> %llu\n", participation,
+         (unsigned long long)LC634__ATTESTED_SLOT, (unsigned long long)(LC634__ATTESTED_SLOT / 8192), (unsigned long long)LC633__FINALIZED_SLOT,
+         (unsigned long long)LC634__FINALIZED_SLOT);
+  g_skip_oracle_prove = true;  // 2^19 rows: see test_ssz_sync_committee
+  try { prove_and_verify(*data, pw); } catch (...) { g_skip_oracle_prove = false; throw; }
+  g_skip_oracle_prove = false;
+}
+static void test_light_client_update() { light_client_update(false); }
+static void test_light_client_update_bad_state_root_panics() { light_client_update(true); }
+
 struct TestCase { const char *name; std::function<void()> fn; bool should_panic; };
 static const TestCase TESTS[] = {
     {"test_merkle_root_2_leaves", test_merkle_root_2_leaves, false},
@@ -265,6 +324,8 @@ static const TestCase TESTS[] = {
     {"test_verify_sync_committee_branch_panics", test_verify_sync_committee_branch_panics, true},
     {"test_read_u32_be_public_input", test_read_u32_be_public_input, false},
     {"test_ssz_sync_committee", test_ssz_sync_committee, false},
+    {"test_light_client_update", test_light_client_update, false},
+    {"test_light_client_update_bad_state_root_panics", test_light_client_update_bad_state_root_panics, true},
 };
 
 int main(int argc, char **argv) {

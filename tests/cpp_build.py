@@ -16,7 +16,8 @@ def build():
     hdr = os.path.join(CPP, "golden_data.hpp")
     gen = os.path.join(CPP, "make_golden_header.py")
     kat = os.path.join(ROOT, "tests", "golden", "sha256_kat.json")
-    if not os.path.exists(hdr) or os.path.getmtime(hdr) < max(os.path.getmtime(gen), os.path.getmtime(kat)):
+    lcu = os.path.join(ROOT, "tests", "golden", "lc_updates.json")
+    if not os.path.exists(hdr) or os.path.getmtime(hdr) < max(os.path.getmtime(gen), os.path.getmtime(kat), os.path.getmtime(lcu)):
         subprocess.run(["python3", gen, hdr], check=True)
     srcs = [os.path.join(CPP, "test_gadgets.cpp")] + [os.path.join(HOST, f) for f in ("gates.cpp", "builder.cpp", "gadgets.cpp")]
     deps = srcs + [hdr] + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [

@@ -9,7 +9,8 @@ CPU_TESTS = [
     "test_merkle_root_2_leaves", "test_merkle_root_4_leaves", "test_merkle_root_8_leaves", "test_merkle_root_16_leaves",
     "test_merkle_root_wrong_root_panics", "test_signing_root", "test_beacon_block_header", "test_verify_finality_branch",
     "test_contract_state", "test_verify_sync_committee_branch", "test_verify_sync_committee_branch_panics",
-    "test_read_u32_be_public_input", "test_ssz_sync_committee",
+    "test_read_u32_be_public_input", "test_ssz_sync_committee", "test_light_client_update",
+    "test_light_client_update_bad_state_root_panics",
 ]
 
 
@@ -27,7 +28,8 @@ def test_gadget_cpu(name):
 
 @pytest.mark.gpu
 def test_gadgets_gpu_all():
-    # BASELINE configs[0] (ContractState) and configs[1] (SyncCommitteeSSZ, 2^19 rows) end to end on the GPU
+    # BASELINE configs[0] (ContractState), configs[1] (SyncCommitteeSSZ, 2^19 rows) and configs[2] (light-client update
+    # 633 -> 634, BLS verifier stubbed) end to end on the GPU
     r = cpp_build.run("gpu", "all", timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     for name in CPU_TESTS:
