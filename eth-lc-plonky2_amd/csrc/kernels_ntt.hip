@@ -1,28 +1,21 @@
 // NTT pass kernels for gfx950 (rows a2, a3, a4 of SURVEY.md section 8): see ntt.hpp for the
-// decomposition.  One workgroup = one 2^L-element slab in LDS (up to 64 KiB, so two
-// workgroups share a CU's 160 KiB), 256 threads, one barrier per radix-2 stage.
+// decomposition.  One workgroup = one 2^L-element slab in LDS (up to 68 KiB with padding, so two
+// workgroups share a CU's 160 KiB), NTT_THREADS threads, one barrier per register step (3-4 stages).
 // Global traffic is one read and one write of the slab per pass, in runs of >= 128 bytes.
 #include "internal.hpp"
 
 namespace lcp2 {
 
 template <bool INV>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassParams p) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassParams p) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   NttPass pass{p};
   const u32 tid = threadIdx.x, wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z + p.z_base;
   pass.template load<INV>(lds, tid, NTT_THREADS, wg, col, z);
   __syncthreads();
-  if (!INV) {
-    for (int b = (int)(p.S + p.B) - 1; b >= (int)p.S; b--) {
-      pass.template stage<false>(lds, tid, NTT_THREADS, (u32)b);
-      __syncthreads();
-    }
-  } else {
-    for (u32 b = p.S; b < p.S + p.B; b++) {
-      pass.template stage<true>(lds, tid, NTT_THREADS, b);
-      __syncthreads();
-    }
+  for (u32 si = 0; si < p.nsteps; si++) {
+    pass.template step<INV>(lds, tid, NTT_THREADS, si);
+    __syncthreads();
   }
   pass.template store<INV>(lds, tid, NTT_THREADS, wg, col, z);
 }
@@ -42,7 +35,7 @@ __global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restri
 }
 
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
-  size_t lds_bytes = (size_t)8 << p.L;
+  size_t lds_bytes = (size_t)8 * ntt_lds_words(p.L);
   dim3 grid(wgs, cols, nz);
   if (inverse) hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds_bytes, s, p);
   else hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds_bytes, s, p);

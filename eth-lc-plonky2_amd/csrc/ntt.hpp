@@ -1,4 +1,4 @@
-// Multi-pass radix-2 NTT over Goldilocks, LDS-staged, written for gfx950.
+// Multi-pass NTT over Goldilocks, LDS-staged with radix-8/16 register steps, written for gfx950.
 //
 // Replaces plonky2_field 0.1.1 fft.rs (`fft_with_options`, `ifft_with_options`),
 // polynomial/mod.rs (`lde`, `coset_fft`, `coset_ifft`) as used by
@@ -24,7 +24,15 @@
 // The forward output order is exactly the Merkle leaf order of plonky2
 // (`reverse_index_bits_in_place` after the LDE), so no transpose pass exists.
 //
-// The pass body is split into load / stage / store phases that take an explicit
+// Inside a slab the B stages of the group run as REGISTER STEPS of r <= 4 stages: a thread pulls the 2^r
+// elements that differ in r consecutive index bits out of LDS, runs the 2^r-point transform in registers
+// (constant twiddles w_16^k held in SGPRs), applies the step twiddle w_{N'}^(m * bitrev(j)) (N' = size of
+// the sub-transform the step starts, m = index bits below the step) and puts them back: 13 stages cost
+// 4 LDS round trips and barriers instead of 13, and the index arithmetic is paid once per 2^r elements.
+// LDS words are padded by one per 16 (lds_phys) so that the bottom step, where each thread owns 16
+// consecutive elements, is bank-conflict free; every other step reads runs of consecutive words.
+//
+// The pass body is split into load / step / store phases that take an explicit
 // thread id: the HIP kernel calls them with a barrier in between, the CPU
 // emulation harness (tests/emu) calls them in loops.
 #pragma once
@@ -33,8 +41,8 @@
 namespace lcp2 {
 
 constexpr u32 NTT_MAX_L = 13;       // slab = 2^13 elements = 64 KiB of LDS
-constexpr u32 NTT_THREADS = 1024;   // 2 workgroups x 16 waves per CU share the 160 KiB LDS: the stages are barrier/latency bound, so
-                                    // occupancy matters more than work per thread (measured LDE: 256 thr 174 ms, 512 thr 132 ms, 1024 thr 123 ms)
+constexpr u32 NTT_THREADS = 512;    // 2 workgroups per CU (2 x 68 KiB of LDS), 16 elements of the slab per thread
+constexpr u32 NTT_MAX_STEPS = 8;
 constexpr u32 NTT_MAX_STRIDED_B = 9;
 constexpr u32 NTT_SEG_BITS = 4;     // 16 x 8 B = 128-byte runs in strided passes
 constexpr u32 NTT_BATCH = 4;        // elements (butterflies) in flight per thread
@@ -54,13 +62,53 @@ struct NttPassParams {
   u32 z_base;                         // coset index of blockIdx.z = 0 (coset-sharded LDE: one launch per leaf block)
   u32 out_block_base;                 // leaf block that sits at offset 0 of `out` (a rank holds blocks [base, base + count))
   u32 L, S, B, g_lo;                  // slab bits, run bits, group bits, bits below the group
-  const u64 *stage_tw;                // w_{2^B}^j (or its inverse), j < 2^(B-1)
+  const u64 *group_tw;                // w_{2^B}^e (or its inverse), e < 2^B: step twiddles
+  u64 wr[8];                          // w_16^k (or inverse), k < 8: constant twiddles of the register transforms
+  u32 nsteps;
+  u32 step_plan;                      // stages per register step, 4 bits each, listed from the top bits of the group down
   TwoLevelTable tw;                   // w_{N_g}^e (or inverse); used when g_lo > 0
   u32 scale_mode;                     // 0 none, 1 scalar, 2 two-level table (per z)
   u64 scale_scalar;
   TwoLevelTable sc;                   // forward: applied at load; inverse: at store
   u64 sc_lo_z_stride, sc_hi_z_stride;
 };
+
+LCP2_HD u32 lds_phys(u32 i) { return i + (i >> 4); }
+LCP2_HD u32 ntt_lds_words(u32 L) { return (1u << L) + ((1u << L) >> 4) + 1; }
+
+// 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out; dit: bit-reversed in -> natural out
+// (wr holds the inverse roots there).  wr[k] = w_16^k.
+template <u32 RB>
+LCP2_HD void ntt_reg_dif(u64 *x, const u64 *wr) {
+  constexpr u32 R = 1u << RB;
+#pragma unroll
+  for (u32 s = 0; s < RB; s++) {
+    const u32 half = R >> (s + 1);
+#pragma unroll
+    for (u32 q = 0; q < R / 2; q++) {
+      const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
+      const u64 a = x[i0], b = x[i1];
+      x[i0] = gl_add(a, b);
+      const u64 d = gl_sub(a, b);
+      x[i1] = i ? gl_mul(d, wr[i * (8 / half)]) : d;
+    }
+  }
+}
+template <u32 RB>
+LCP2_HD void ntt_reg_dit(u64 *x, const u64 *wr) {
+  constexpr u32 R = 1u << RB;
+#pragma unroll
+  for (u32 s = RB; s-- > 0;) {
+    const u32 half = R >> (s + 1);
+#pragma unroll
+    for (u32 q = 0; q < R / 2; q++) {
+      const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
+      const u64 a = x[i0], b = i ? gl_mul(x[i1], wr[i * (8 / half)]) : x[i1];
+      x[i0] = gl_add(a, b);
+      x[i1] = gl_sub(a, b);
+    }
+  }
+}
 
 LCP2_HD u64 two_level(const TwoLevelTable &t, u64 e) {
   return gl_mul(t.lo[e & ((1ull << t.h) - 1)], t.hi[e >> t.h]);
@@ -122,42 +170,58 @@ struct NttPass {
         } else {
           if (p.g_lo) x = gl_mul(x, group_twiddle(wg, i));
         }
-        lds[i] = x;
+        lds[lds_phys(i)] = x;
       }
     }
   }
 
-  // one radix-2 stage on local bit b (S <= b < S + B)
-  template <bool INV>
-  LCP2_HD void stage(u64 *lds, u32 tid, u32 nthr, u32 b) const {
-    const u32 half = 1u << (p.L - 1);
-    const u32 kb = b - p.S;  // bit position inside the group
-    for (u32 q0 = tid; q0 < half; q0 += nthr * NTT_BATCH) {
-      u32 i0[NTT_BATCH];
-      u64 a[NTT_BATCH], c[NTT_BATCH], w[NTT_BATCH];
+  // Register step over the RB group bits whose top one is kb_top (group-relative): see the header comment.
+  template <bool INV, u32 RB>
+  LCP2_HD void step_r(u64 *lds, u32 tid, u32 nthr, u32 kb_top) const {
+    constexpr u32 R = 1u << RB;
+    const u32 mbits = kb_top + 1 - RB;          // group bits below the step
+    const u32 P = p.S + mbits;                  // local bit position of the step's lowest bit
+    const u32 ngroups = 1u << (p.L - RB);
+    const u32 tw_shift = p.B - kb_top - 1;      // w_{N'} = w_{2^B}^(2^tw_shift)
+    for (u32 g = tid; g < ngroups; g += nthr) {
+      const u32 base = ((g >> P) << (P + RB)) | (g & ((1u << P) - 1));
+      const u32 m = (base >> p.S) & ((1u << mbits) - 1);
+      u64 x[R], tw[R];
 #pragma unroll
-      for (u32 j = 0; j < NTT_BATCH; j++) {
-        u32 q = q0 + j * nthr;
-        if (q >= half) q = 0;
-        i0[j] = ((q >> b) << (b + 1)) | (q & ((1u << b) - 1));
-        u32 k = (i0[j] >> p.S) & ((1u << kb) - 1);
-        w[j] = p.stage_tw[(u64)k << (p.B - 1 - kb)];
-        a[j] = lds[i0[j]];
-        c[j] = lds[i0[j] | (1u << b)];
+      for (u32 j = 0; j < R; j++) x[j] = lds[lds_phys(base | (j << P))];
+      if (mbits) {
+#pragma unroll
+        for (u32 j = 1; j < R; j++) tw[j] = p.group_tw[(u64)(m * bitrev32(j, RB)) << tw_shift];
       }
+      if (!INV) {
+        ntt_reg_dif<RB>(x, p.wr);
+        if (mbits) {
 #pragma unroll
-      for (u32 j = 0; j < NTT_BATCH; j++) {
-        if (q0 + j * nthr >= half) continue;
-        const u32 i1 = i0[j] | (1u << b);
-        if (!INV) {
-          lds[i0[j]] = gl_add(a[j], c[j]);
-          lds[i1] = gl_mul(gl_sub(a[j], c[j]), w[j]);
-        } else {
-          u64 t = gl_mul(c[j], w[j]);
-          lds[i0[j]] = gl_add(a[j], t);
-          lds[i1] = gl_sub(a[j], t);
+          for (u32 j = 1; j < R; j++) x[j] = gl_mul(x[j], tw[j]);
         }
+      } else {
+        if (mbits) {
+#pragma unroll
+          for (u32 j = 1; j < R; j++) x[j] = gl_mul(x[j], tw[j]);
+        }
+        ntt_reg_dit<RB>(x, p.wr);
       }
+#pragma unroll
+      for (u32 j = 0; j < R; j++) lds[lds_phys(base | (j << P))] = x[j];
+    }
+  }
+  // step si of the pass in execution order (forward: from the top bits down; inverse: from the bottom up)
+  template <bool INV>
+  LCP2_HD void step(u64 *lds, u32 tid, u32 nthr, u32 si) const {
+    const u32 idx = INV ? p.nsteps - 1 - si : si;
+    u32 above = 0;
+    for (u32 i = 0; i < idx; i++) above += (p.step_plan >> (4 * i)) & 15;
+    const u32 kb_top = p.B - 1 - above;
+    switch ((p.step_plan >> (4 * idx)) & 15) {
+      case 1: step_r<INV, 1>(lds, tid, nthr, kb_top); break;
+      case 2: step_r<INV, 2>(lds, tid, nthr, kb_top); break;
+      case 3: step_r<INV, 3>(lds, tid, nthr, kb_top); break;
+      default: step_r<INV, 4>(lds, tid, nthr, kb_top); break;
     }
   }
 
@@ -171,7 +235,7 @@ struct NttPass {
       for (u32 j = 0; j < NTT_BATCH; j++) {
         u32 i = i0 + j * nthr;
         if (i >= n) i = 0;
-        v[j] = lds[i];
+        v[j] = lds[lds_phys(i)];
         tw[j] = 1;
         if (!INV) {
           if (p.g_lo) tw[j] = group_twiddle(wg, i);
@@ -213,6 +277,27 @@ inline int ntt_plan(u32 lg, NttGroup out[8]) {
     out[n++] = NttGroup{B, pos, B + S, S};
   }
   out[n++] = NttGroup{NTT_MAX_L, 0, NTT_MAX_L, 0};
+  return n;
+}
+
+// Cuts the B stages of a group into register steps (top-down order).  The bottom step of a contiguous group
+// (S = 0) takes 4 bits (the padded layout makes it conflict free), everything above it is cut into 3s with 4s
+// absorbing the remainder, so that no step starts at local bit 1..3.
+inline u32 ntt_step_plan(u32 B, u32 S, u32 &plan) {
+  unsigned char up[NTT_MAX_STEPS];  // bottom-up
+  u32 n = 0, left = B;
+  if (S == 0 && left >= 4) { up[n++] = 4; left -= 4; }
+  while (left) {
+    u32 r;
+    if (left <= 4) r = left;
+    else if (left % 3 == 0) r = 3;
+    else if (left == 5) r = 3;
+    else r = 4;
+    up[n++] = (unsigned char)r;
+    left -= r;
+  }
+  plan = 0;
+  for (u32 i = 0; i < n; i++) plan |= (u32)up[n - 1 - i] << (4 * i);
   return n;
 }
 

@@ -31,13 +31,19 @@ struct NttHost {
     return std::string(what) + ":" + std::to_string(a) + ":" + std::to_string(b) + ":" + std::to_string(c);
   }
 
-  const u64 *stage_table(u32 B, bool inv) {
-    if (B == 0) B = 1;
-    return be.table(key("stage", B, inv), [=] {
+  // everything a pass needs for its register steps: w_{2^B}^e table, the w_16^k constants and the step plan
+  void set_group(NttPassParams &p, bool inv) {
+    const u32 B = p.B;
+    p.group_tw = be.table(key("group", B, inv), [=] {
       u64 w = gl_root_of_unity(B);
       if (inv) w = gl_inv(w);
-      return make_pow_table(w, 1, B > 1 ? (size_t)1 << (B - 1) : 1);
+      return make_pow_table(w, 1, (size_t)1 << B);
     });
+    u64 w16 = gl_root_of_unity(4);
+    if (inv) w16 = gl_inv(w16);
+    u64 cur = 1;
+    for (int k = 0; k < 8; k++) { p.wr[k] = cur; cur = gl_mul(cur, w16); }
+    p.nsteps = ntt_step_plan(p.B, p.S, p.step_plan);
   }
   TwoLevelTable root_table(u32 lg, bool inv) {
     TwoLevelTable t;
@@ -109,7 +115,7 @@ struct NttHost {
       NttPassParams p{};
       bool first = gi == 0;
       p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
-      p.stage_tw = stage_table(g.B, false);
+      set_group(p, false);
       if (g.g_lo) p.tw = root_table(g.g_lo + g.B, false);
       u32 wgs, nz;
       if (first) {
@@ -149,7 +155,7 @@ struct NttHost {
       const NttGroup &g = groups[gi];
       NttPassParams p{};
       p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
-      p.stage_tw = stage_table(g.B, true);
+      set_group(p, true);
       if (g.g_lo) p.tw = root_table(g.g_lo + g.B, true);
       bool firstpass = gi == ng - 1, lastpass = gi == 0;
       p.in = firstpass ? in : out; p.in_col_stride = firstpass ? in_col_stride : out_col_stride;

@@ -1,4 +1,4 @@
-// TEST HARNESS (not product code): runs the portable load/stage/store phases of the
+// TEST HARNESS (not product code): runs the portable load/step/store phases of the
 // device kernels on the CPU, thread by thread, so that index logic and field
 // arithmetic of csrc/*.hpp can be checked against the oracle without a GPU.
 // Built by tests/emu_lib.py with g++; never loaded by the package.
@@ -20,19 +20,14 @@ struct EmuBackend {
   }
   void launch_pass(bool inv, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
     NttPass pass{p};
-    std::vector<u64> lds((size_t)1 << p.L);
+    std::vector<u64> lds(ntt_lds_words(p.L));
     const u32 T = NTT_THREADS;
     for (u32 z = p.z_base; z < p.z_base + nz; z++)
       for (u32 c = 0; c < cols; c++)
         for (u32 w = 0; w < wgs; w++) {
           for (u32 t = 0; t < T; t++) inv ? pass.load<true>(lds.data(), t, T, w, c, z) : pass.load<false>(lds.data(), t, T, w, c, z);
-          if (!inv) {
-            for (int b = (int)(p.S + p.B) - 1; b >= (int)p.S; b--)
-              for (u32 t = 0; t < T; t++) pass.stage<false>(lds.data(), t, T, (u32)b);
-          } else {
-            for (u32 b = p.S; b < p.S + p.B; b++)
-              for (u32 t = 0; t < T; t++) pass.stage<true>(lds.data(), t, T, b);
-          }
+          for (u32 si = 0; si < p.nsteps; si++)
+            for (u32 t = 0; t < T; t++) inv ? pass.step<true>(lds.data(), t, T, si) : pass.step<false>(lds.data(), t, T, si);
           for (u32 t = 0; t < T; t++) inv ? pass.store<true>(lds.data(), t, T, w, c, z) : pass.store<false>(lds.data(), t, T, w, c, z);
         }
   }
