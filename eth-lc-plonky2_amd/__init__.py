@@ -8,6 +8,7 @@ directory name follows the project ("eth-lc-plonky2_amd"); import it as
 from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Params, load_library, standard_params,  # noqa: F401
                       MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P)
 from .build import build_native  # noqa: F401
+from . import binding  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402
 from . import batch  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402

@@ -47,6 +47,12 @@ class CircuitDesc(ctypes.Structure):
 _lib = None
 
 
+class ChallengerState(ctypes.Structure):
+    """lcp2_challenger: plonky2's Challenger { sponge_state, input_buffer, output_buffer } by value"""
+    _fields_ = [("sponge", ctypes.c_uint64 * 12), ("input", ctypes.c_uint64 * 8), ("output", ctypes.c_uint64 * 8),
+                ("input_len", ctypes.c_uint32), ("output_len", ctypes.c_uint32)]
+
+
 def _share_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so.  Two HIP runtimes in one
     process cannot both own the GPU, and torch tensors / streams are only meaningful to the runtime that made
@@ -109,6 +115,10 @@ def load_library():
         "lcp2_circuit_digest": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_proof_words": (c.c_size_t, [c.POINTER(Params)]),
         "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p]),
+        "lcp2_commit_wires": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]),
+        "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_fri_open": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
         "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(c.c_int)]),
         "lcp2_last_challenges": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
@@ -378,6 +388,36 @@ class CircuitData:
             wp = ctypes.c_void_p(wires)
         self._check(self.lib.lcp2_prove(self.handle, wp, mem, _ptr(pis), _ptr(proof)))
         return proof
+
+    # ---- the seams of data.prove() one by one (the caller runs the Fiat-Shamir transcript)
+    def _cap(self):
+        return np.zeros((1 << self.circ.params.cap_height, 4), dtype=np.uint64)
+
+    def commit_wires(self, wires, mem=MEM_HOST):
+        cap = self._cap()
+        if mem == MEM_HOST:
+            self._staged_wires = _np_u64(wires)  # stays alive until the proof is finished
+            wp = _ptr(self._staged_wires)
+        else:
+            wp = ctypes.c_void_p(wires)
+        self._check(self.lib.lcp2_commit_wires(self.handle, wp, mem, _ptr(cap)))
+        return cap
+
+    def perm_zs(self, betas, gammas):
+        cap, b, g = self._cap(), _np_u64(betas), _np_u64(gammas)
+        self._check(self.lib.lcp2_perm_zs(self.handle, _ptr(b), _ptr(g), _ptr(cap)))
+        return cap
+
+    def quotient(self, alphas, public_inputs):
+        cap, a, pis = self._cap(), _np_u64(alphas), _np_u64(public_inputs)
+        self._check(self.lib.lcp2_quotient(self.handle, _ptr(a), _ptr(pis), _ptr(cap)))
+        return cap
+
+    def fri_open(self, zeta, challenger_state, proof):
+        """proof: uint64 array of proof_words; words from the openings on are written; challenger_state is updated"""
+        z = _np_u64(zeta)
+        assert proof.dtype == np.uint64 and proof.size == self.proof_words and proof.flags.c_contiguous
+        self._check(self.lib.lcp2_fri_open(self.handle, _ptr(z), ctypes.byref(challenger_state), _ptr(proof)))
 
     def verify(self, proof, public_inputs):
         """data.verify(proof): raises ProofRejected like the reference's unwrap()"""

@@ -73,6 +73,15 @@ class HostChallenger {
     for (int i = 0; i < nin_; i++) state[i] = in_[i];
     pos = (u32)nin_;
   }
+  // plonky2's Challenger { sponge_state, input_buffer, output_buffer } for the staged C ABI (lcp2_challenger)
+  void save(u64 sponge[12], u64 input[8], uint32_t &input_len, u64 output[8], uint32_t &output_len) const {
+    memcpy(sponge, s_, sizeof s_); memcpy(input, in_, sizeof in_); memcpy(output, out_, sizeof out_);
+    input_len = (uint32_t)nin_; output_len = (uint32_t)nout_;
+  }
+  void load(const u64 sponge[12], const u64 input[8], uint32_t input_len, const u64 output[8], uint32_t output_len) {
+    memcpy(s_, sponge, sizeof s_); memcpy(in_, input, sizeof in_); memcpy(out_, output, sizeof out_);
+    nin_ = (int)input_len; nout_ = (int)output_len;
+  }
 
  private:
   void duplex() {

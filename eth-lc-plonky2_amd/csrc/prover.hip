@@ -33,6 +33,9 @@ struct lcp2_circuit {
   std::vector<std::vector<u64>> fri_level_off;
   std::vector<DevBuf> fri_d_level_off;
   DevBuf q_idx, q_buf;
+  // staged proving (lcp2_commit_wires -> lcp2_perm_zs -> lcp2_quotient -> lcp2_fri_open)
+  const u64 *d_wires_cur = nullptr;
+  int stage = 0;
 };
 
 namespace {
@@ -284,54 +287,51 @@ int eval_columns(lcp2_circuit *c, const u64 *coeffs, u32 ncols, gl2 z, u64 *d_ou
 }
 }  // namespace
 
-extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, uint64_t *proof_) {
-  if (!c || !wires_in_ || !proof_ || (c->npi && !public_inputs_)) return LCP2_E_INVALID;
-  if (!c->ctx) return LCP2_E_NODEVICE;  // verifier-only circuit
-  const u64 *wires_in = (const u64 *)wires_in_, *public_inputs = (const u64 *)public_inputs_;
-  u64 *proof = (u64 *)proof_;
-  lcp2_ctx *ctx = c->ctx;
-  LCP2_HIP(ctx, hipSetDevice(ctx->device));
-  const lcp2_params &p = c->p;
-  const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits;
-  const u32 lgN = p.degree_bits + p.rate_bits, W = p.num_wires, NR = p.num_routed_wires, NC = p.num_constants, CH = p.num_challenges,
-            Q = p.quotient_degree_factor, npp = npp_of(p), nchunks = npp + 1, ncs = NC + NR;
-  const ProofLayout L(p);
-  memset(proof, 0, L.total * 8);
-  hipStream_t s = ctx->stream;
-  DeviceNttBackend be{ctx};
-  NttHost<DeviceNttBackend> ntt(be);
-  HostPoseidon &H = HostPoseidon::get();
+// ---- the four seams of SURVEY section 8b: each is a function of its inputs and of the commitments made by the
+// stages before it (held by the circuit handle); lcp2_prove is their composition under the Fiat-Shamir transcript.
+namespace {
+#define LCP2_STAGE_PROLOGUE \
+    lcp2_ctx *ctx = c->ctx; \
+    LCP2_HIP(ctx, hipSetDevice(ctx->device)); \
+    const lcp2_params &p = c->p; \
+    const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits; \
+    const u32 lgN = p.degree_bits + p.rate_bits, W = p.num_wires, NR = p.num_routed_wires, NC = p.num_constants, CH = p.num_challenges, \
+              Q = p.quotient_degree_factor, npp = npp_of(p), nchunks = npp + 1, ncs = NC + NR; \
+    const ProofLayout L(p); \
+    hipStream_t s = ctx->stream; \
+    DeviceNttBackend be{ctx}; \
+    NttHost<DeviceNttBackend> ntt(be); \
+    (void)N; (void)lgN; (void)W; (void)NR; (void)NC; (void)CH; (void)Q; (void)npp; (void)nchunks; (void)ncs; (void)L; (void)s; (void)ntt;
 
-  std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
-  for (u32 i = 0; i < c->npi; i++) pis[i] = gl_canon(public_inputs[i]);
-  u64 pi_hash[4];
-  H.hash_no_pad(pis.data(), c->npi, pi_hash);
-
-  // small device block: [betas CH | gammas CH | alphas CH | pis]
-  u64 *d_small = c->small.u();
-  u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
-  if (c->npi) LCP2_HIP(ctx, hipMemcpyAsync(d_pis, pis.data(), c->npi * 8, hipMemcpyHostToDevice, s));
-
-  // ---- wires commitment
+// PolynomialBatch::from_values on the witness (K1-K4)
+int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, u64 *cap_out) {
+  LCP2_STAGE_PROLOGUE
   const u64 *d_wires = wires_in;
   if (wires_mem == LCP2_MEM_HOST) {
     LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
     LCP2_HIP(ctx, hipMemcpyAsync(c->wires_vals.p, wires_in, (size_t)W * n * 8, hipMemcpyHostToDevice, s));
     d_wires = c->wires_vals.u();
   }
+  c->stage = 0;
   LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
-  LCP2_TRY(download(ctx, proof + L.wires_cap, c->wires.cap_dev(), L.capw * 8));
+  LCP2_TRY(download(ctx, cap_out, c->wires.cap_dev(), L.capw * 8));
+  c->d_wires_cur = d_wires;
+  c->stage = 1;
+  return LCP2_OK;
+}
 
-  HostChallenger ch;
-  ch.observe_n(c->digest, 4);
-  ch.observe_n(pi_hash, 4);
-  ch.observe_n(proof + L.wires_cap, L.capw);
-  u64 betas[4] = {0}, gammas[4] = {0}, alphas[4] = {0};
-  for (u32 k = 0; k < CH; k++) betas[k] = ch.get();
-  for (u32 k = 0; k < CH; k++) gammas[k] = ch.get();
-  LCP2_HIP(ctx, hipMemcpyAsync(d_betas, betas, CH * 8, hipMemcpyHostToDevice, s));
-  LCP2_HIP(ctx, hipMemcpyAsync(d_gammas, gammas, CH * 8, hipMemcpyHostToDevice, s));
-
+// wires_permutation_partial_products_and_zs + commitment (K5, K1-K4)
+int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap_out) {
+  LCP2_STAGE_PROLOGUE
+  if (c->stage < 1) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
+  const u64 *d_wires = c->d_wires_cur;
+  u64 *d_small = c->small.u();
+  u64 *d_betas = d_small, *d_gammas = d_small + 4;
+  u64 bc[4] = {0}, gc[4] = {0};
+  for (u32 k = 0; k < CH; k++) { bc[k] = gl_canon(betas[k]); gc[k] = gl_canon(gammas[k]); }
+  LCP2_HIP(ctx, hipMemcpyAsync(d_betas, bc, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_gammas, gc, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipStreamSynchronize(s));
   // ---- K5: Z and partial products on H
   {
     PermArgs a{};
@@ -347,11 +347,24 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   }
   LCP2_HIP(ctx, hipGetLastError());
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
-  LCP2_TRY(download(ctx, proof + L.zs_cap, c->zs.cap_dev(), L.capw * 8));
-  ch.observe_n(proof + L.zs_cap, L.capw);
-  for (u32 k = 0; k < CH; k++) alphas[k] = ch.get();
-  LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, alphas, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_TRY(download(ctx, cap_out, c->zs.cap_dev(), L.capw * 8));
+  c->stage = 2;
+  return LCP2_OK;
+}
 
+// compute_quotient_polys + commitment (K6, K1-K4)
+int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs, u64 *cap_out) {
+  LCP2_STAGE_PROLOGUE
+  if (c->stage < 2) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
+  u64 *d_small = c->small.u();
+  u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
+  std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
+  for (u32 i = 0; i < c->npi; i++) pis[i] = gl_canon(public_inputs[i]);
+  u64 ac[4] = {0};
+  for (u32 k = 0; k < CH; k++) ac[k] = gl_canon(alphas[k]);
+  if (c->npi) LCP2_HIP(ctx, hipMemcpyAsync(d_pis, pis.data(), c->npi * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, ac, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipStreamSynchronize(s));
   // ---- K6: quotient values on the coset, coset iNTT, chunking, commitment
   {
     QuotientArgs a{};
@@ -375,11 +388,18 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   if (be.status) return be.status;
   // N = Q n: the 8n coefficients of challenge c are exactly its Q chunks of n coefficients, already contiguous
   LCP2_TRY(commit_coeffs_dev(ctx, c->quot.coeffs.u(), CH * Q, p.degree_bits, p.rate_bits, p.cap_height, &c->quot, false));
-  LCP2_TRY(download(ctx, proof + L.quot_cap, c->quot.cap_dev(), L.capw * 8));
-  ch.observe_n(proof + L.quot_cap, L.capw);
-  const gl2 zeta = ch.get_ext();
-  const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
+  LCP2_TRY(download(ctx, cap_out, c->quot.cap_dev(), L.capw * 8));
+  c->stage = 3;
+  return LCP2_OK;
+}
 
+// OpeningSet::new + PolynomialBatch::prove_openings (K7-K9, a13).  `ch` has observed everything up to the quotient cap and
+// zeta was drawn from it; on return it has absorbed the openings, the FRI caps, the final polynomial and the PoW witness and
+// produced the query indices.  Writes proof words [op_constants, total).
+int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl2 &alpha, gl2 *fri_betas, u64 &pow_witness, std::vector<u64> &idx) {
+  LCP2_STAGE_PROLOGUE
+  if (c->stage < 3) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
+  const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
   // ---- K7a: openings
   lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
   {
@@ -406,7 +426,7 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   ch.observe_n(proof + L.op_zs_next, 2 * CH);
 
   // ---- K7b: final polynomial of the batched opening
-  const gl2 alpha = ch.get_ext();
+  alpha = ch.get_ext();
   {
     const u32 total_polys = ncs + W + CH * (1 + npp) + CH * Q;
     const u32 h = (p.degree_bits + 1) / 2;
@@ -439,7 +459,6 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   LCP2_HIP(ctx, hipGetLastError());
 
   // ---- K8: FRI commit phase
-  gl2 fri_betas[LCP2_MAX_FRI_LAYERS];
   u64 m = n;  // number of (possibly) non-zero coefficients; the zero padding to 8m is implicit
   u64 shift = GL_GENERATOR;
   int cur = 0;
@@ -483,7 +502,7 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   ch.observe_n(proof + L.final_poly, 2 * L.final_len);
 
   // ---- K9: proof of work, minimum witness
-  u64 pow_witness = 0;
+  pow_witness = 0;
   {
     PowArgs a{};
     ch.pow_state(a.state, a.pos);
@@ -511,7 +530,7 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
 
   // ---- query phase: gather leaves and Merkle paths on the device, one copy back
   const u32 Qn = p.num_query_rounds;
-  std::vector<u64> idx(Qn * (1 + p.num_fri_layers));
+  idx.assign(Qn * (1 + p.num_fri_layers), 0);
   for (u32 q = 0; q < Qn; q++) {
     u64 x = ch.get() % N;
     idx[q] = x;
@@ -557,6 +576,44 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
       }
     }
   }
+  return LCP2_OK;
+}
+}  // namespace
+
+extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, uint64_t *proof_) {
+  if (!c || !wires_in_ || !proof_ || (c->npi && !public_inputs_)) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;  // verifier-only circuit
+  const u64 *public_inputs = (const u64 *)public_inputs_;
+  u64 *proof = (u64 *)proof_;
+  const lcp2_params &p = c->p;
+  const u32 CH = p.num_challenges;
+  const ProofLayout L(p);
+  memset(proof, 0, L.total * 8);
+  HostPoseidon &H = HostPoseidon::get();
+  std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
+  for (u32 i = 0; i < c->npi; i++) pis[i] = gl_canon(public_inputs[i]);
+  u64 pi_hash[4];
+  H.hash_no_pad(pis.data(), c->npi, pi_hash);
+
+  LCP2_TRY(stage_wires(c, (const u64 *)wires_in_, wires_mem, proof + L.wires_cap));
+  HostChallenger ch;
+  ch.observe_n(c->digest, 4);
+  ch.observe_n(pi_hash, 4);
+  ch.observe_n(proof + L.wires_cap, L.capw);
+  u64 betas[4] = {0}, gammas[4] = {0}, alphas[4] = {0};
+  for (u32 k = 0; k < CH; k++) betas[k] = ch.get();
+  for (u32 k = 0; k < CH; k++) gammas[k] = ch.get();
+  LCP2_TRY(stage_perm_zs(c, betas, gammas, proof + L.zs_cap));
+  ch.observe_n(proof + L.zs_cap, L.capw);
+  for (u32 k = 0; k < CH; k++) alphas[k] = ch.get();
+  LCP2_TRY(stage_quotient(c, alphas, pis.data(), proof + L.quot_cap));
+  ch.observe_n(proof + L.quot_cap, L.capw);
+  const gl2 zeta = ch.get_ext();
+  gl2 alpha, fri_betas[LCP2_MAX_FRI_LAYERS];
+  u64 pow_witness = 0;
+  std::vector<u64> idx;
+  LCP2_TRY(stage_fri_open(c, zeta, ch, proof, alpha, fri_betas, pow_witness, idx));
+  const u32 Qn = p.num_query_rounds;
   // record the transcript for stage-wise parity tests
   u64 *lc = c->last_challenges;
   memset(lc, 0, sizeof c->last_challenges);
@@ -565,5 +622,35 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   for (u32 l = 0; l < p.num_fri_layers; l++) { lc[16 + 2 * l] = fri_betas[l].c0; lc[17 + 2 * l] = fri_betas[l].c1; }
   lc[32] = pow_witness;
   for (u32 q = 0; q < Qn; q++) lc[33 + q] = idx[q];
+  return LCP2_OK;
+}
+
+// ---- C ABI of the seams (include/lcp2.h)
+extern "C" int lcp2_commit_wires(lcp2_circuit *c, const uint64_t *wires, lcp2_mem mem, uint64_t *cap) {
+  if (!c || !wires || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_wires(c, (const u64 *)wires, mem, (u64 *)cap);
+}
+extern "C" int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap) {
+  if (!c || !betas || !gammas || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_perm_zs(c, (const u64 *)betas, (const u64 *)gammas, (u64 *)cap);
+}
+extern "C" int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs, uint64_t *cap) {
+  if (!c || !alphas || !cap || (c->npi && !public_inputs)) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_quotient(c, (const u64 *)alphas, (const u64 *)public_inputs, (u64 *)cap);
+}
+extern "C" int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *chs, uint64_t *proof) {
+  if (!c || !zeta || !chs || !proof) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  HostChallenger ch;
+  ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
+  gl2 alpha, fri_betas[LCP2_MAX_FRI_LAYERS];
+  u64 pow_witness = 0;
+  std::vector<u64> idx;
+  LCP2_TRY(stage_fri_open(c, gl2_make(gl_canon(zeta[0]), gl_canon(zeta[1])), ch, (u64 *)proof, alpha, fri_betas, pow_witness, idx));
+  ch.save((u64 *)chs->sponge, (u64 *)chs->input, chs->input_len, (u64 *)chs->output, chs->output_len);
   return LCP2_OK;
 }

@@ -237,6 +237,29 @@ size_t lcp2_proof_words(const lcp2_params *p);
  * smallest valid one (plonky2 searches with a nondeterministic find_any). */
 int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const uint64_t *public_inputs, uint64_t *proof);
 
+/* ---- the seams inside data.prove() a plonky2 fork binds one by one; lcp2_prove is exactly their
+ * composition under the Fiat-Shamir transcript, and the caller keeps its own Challenger in between.  The commitments
+ * stay on the device inside the circuit handle; the calls must come in this order (LCP2_E_INVALID otherwise).
+ *   lcp2_commit_wires  PolynomialBatch::from_values(wires)                        -> wires cap             (K1-K4)
+ *   lcp2_perm_zs       wires_permutation_partial_products_and_zs + from_values    -> Z/partial-product cap (K5, K1-K4)
+ *   lcp2_quotient      compute_quotient_polys + from_coeffs                       -> quotient cap          (K6, K1-K4)
+ *   lcp2_fri_open      OpeningSet::new + PolynomialBatch::prove_openings           -> openings + FriProof   (K7-K9, a13)
+ * betas/gammas/alphas: num_challenges base-field elements each; caps: 4 << cap_height words. */
+int lcp2_commit_wires(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, uint64_t *cap);
+int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap);
+int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs, uint64_t *cap);
+/* plonky2's Challenger { sponge_state, input_buffer, output_buffer } (iop/challenger.rs), by value */
+typedef struct {
+  uint64_t sponge[12];
+  uint64_t input[8];
+  uint64_t output[8];
+  uint32_t input_len, output_len;
+} lcp2_challenger;
+/* ch: state after observing the quotient cap and drawing zeta; updated to the state after the query indices were
+ * drawn.  proof: a buffer of lcp2_proof_words(); words from the openings to the end are written (the three caps in
+ * front of them are the caller's). */
+int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *ch, uint64_t *proof);
+
 /* data.verify(proof): host only (no device work).  LCP2_OK or LCP2_E_VERIFY; *failed_check (nullable):
  * 1 encoding, 2 proof of work, 3 vanishing identity, 4 initial Merkle proof, 5 FRI consistency,
  * 6 FRI layer Merkle proof, 7 final polynomial. */

@@ -113,3 +113,91 @@ def test_large_proof_verifies(gpu_ctx):
     with pytest.raises(m.ProofRejected):
         data.verify(proof, wrong)
     data.close()
+
+
+class _Challenger:
+    """Challenger<F, PoseidonHash> on the oracle's permutation: the transcript a plonky2 fork keeps on its own side
+    when it binds the seams one by one."""
+    P = (1 << 64) - (1 << 32) + 1
+
+    def __init__(self, oracle):
+        self.o, self.s, self.inp, self.out = oracle, np.zeros(12, dtype=np.uint64), [], []
+
+    def observe(self, xs):
+        for x in np.asarray(xs, dtype=np.uint64).ravel():
+            self.out = []
+            self.inp.append(int(x) % self.P)
+            if len(self.inp) == 8:
+                self._duplex()
+
+    def _duplex(self):
+        for i, v in enumerate(self.inp):
+            self.s[i] = v
+        self.inp = []
+        self.o.orc_poseidon_permute(oracle_lib.vp(self.s))
+        self.out = [int(v) for v in self.s[:8]]
+
+    def get(self, k=1):
+        r = []
+        for _ in range(k):
+            if self.inp or not self.out:
+                self._duplex()
+            r.append(self.out.pop())
+        return np.array(r, dtype=np.uint64)
+
+    def state(self, m):
+        st = m.binding.ChallengerState()
+        for i in range(12):
+            st.sponge[i] = int(self.s[i])
+        for i, v in enumerate(self.inp):
+            st.input[i] = v
+        for i, v in enumerate(self.out):
+            st.output[i] = v
+        st.input_len, st.output_len = len(self.inp), len(self.out)
+        return st
+
+
+def test_staged_seams_compose_to_prove(gpu_ctx, oracle):
+    """lcp2_commit_wires -> lcp2_perm_zs -> lcp2_quotient -> lcp2_fri_open, with the transcript run by the
+    caller, give the proof lcp2_prove gives; calling a seam before its predecessor is LCP2_E_INVALID."""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(10, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=77)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    want = data.prove(wires, pis)
+    ch = data.last_challenges()
+    with pytest.raises(m.Lcp2Error):  # nothing committed yet on a fresh handle
+        m.CircuitData.build(gpu_ctx, circ).perm_zs([1, 2], [3, 4])
+
+    capw = 4 << params.cap_height
+    proof = np.zeros(data.proof_words, dtype=np.uint64)
+    digest, _ = data.digest()
+    pi_hash = np.zeros(4, dtype=np.uint64)
+    p = np.asarray(pis, dtype=np.uint64)
+    oracle.orc_hash_no_pad(oracle_lib.vp(p), len(p), oracle_lib.vp(pi_hash))
+    t = _Challenger(oracle)
+    t.observe(digest)
+    t.observe(pi_hash)
+    proof[0:capw] = data.commit_wires(wires).ravel()
+    t.observe(proof[0:capw])
+    betas, gammas = t.get(2), t.get(2)
+    assert list(betas) == list(ch["betas"][:2]) and list(gammas) == list(ch["gammas"][:2])
+    proof[capw:2 * capw] = data.perm_zs(betas, gammas).ravel()
+    t.observe(proof[capw:2 * capw])
+    alphas = t.get(2)
+    proof[2 * capw:3 * capw] = data.quotient(alphas, pis).ravel()
+    t.observe(proof[2 * capw:3 * capw])
+    zeta = t.get(2)
+    assert list(zeta) == list(ch["zeta"])
+    st = t.state(m)
+    data.fri_open(zeta, st, proof)
+    assert _first_mismatch(m, params, proof, want) is None, _first_mismatch(m, params, proof, want)
+    data.verify(proof, pis)
+    # the returned transcript state is the one after the last query index was drawn: its next output differs from the
+    # state that went in, and the seam is deterministic
+    st2 = t.state(m)
+    proof2 = np.zeros_like(proof)
+    proof2[:3 * capw] = proof[:3 * capw]
+    data.fri_open(zeta, st2, proof2)
+    assert (proof2 == proof).all() and list(st2.sponge) == list(st.sponge) and list(st.sponge) != [int(v) for v in t.s]
+    data.close()
