@@ -201,3 +201,45 @@ def test_staged_seams_compose_to_prove(gpu_ctx, oracle):
     data.fri_open(zeta, st2, proof2)
     assert (proof2 == proof).all() and list(st2.sponge) == list(st.sponge) and list(st.sponge) != [int(v) for v in t.s]
     data.close()
+
+
+def _variant(m, degree_bits, **kw):
+    p = m.standard_params(degree_bits, 4)
+    arities = kw.pop("fri_arity_bits", None)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    if arities is not None:
+        p.num_fri_layers = len(arities)
+        for i in range(8):
+            p.fri_arity_bits[i] = arities[i] if i < len(arities) else 0
+    return p
+
+
+@pytest.mark.parametrize("name,degree_bits,kw", [
+    ("cap_height_0", 8, dict(cap_height=0)),
+    ("cap_height_1_one_challenge", 9, dict(cap_height=1, num_challenges=1)),
+    ("cap_at_fri_limit", 7, dict(cap_height=5, fri_arity_bits=[3, 2])),
+    ("mixed_arities", 10, dict(fri_arity_bits=[3, 1, 2, 2], num_query_rounds=9, proof_of_work_bits=7)),
+    ("arity_32_no_layers_after", 9, dict(fri_arity_bits=[5], num_query_rounds=5)),
+    ("no_fri_layers", 5, dict(fri_arity_bits=[], num_query_rounds=3, proof_of_work_bits=3)),
+    ("rate_bits_4", 8, dict(rate_bits=4, quotient_degree_factor=16, fri_arity_bits=[4, 2])),
+    ("wide_trace", 8, dict(num_wires=150)),
+    ("max_queries", 8, dict(num_query_rounds=64)),
+])
+def test_nonstandard_params_equal_oracle(gpu_ctx, oracle, name, degree_bits, kw):
+    """n, W, rate_bits, cap_height, quotient_degree_factor, the FRI schedule, query count and PoW bits are run-time
+    parameters of every kernel: the GPU proof equals the oracle's for each variant.  (rate_bits < 3 is not in
+    the list: the synthetic gate set's selector groups are laid out for constraint degree 9 = quotient_degree_factor 8.)"""
+    import eth_lc_plonky2_amd as m
+    params = _variant(m, degree_bits, **dict(kw))
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=500 + degree_bits)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    assert oc.check_witness(wires, pis)[0] == 0
+    want = oc.prove(wires, pis)
+    assert oc.verify(want, pis) == 0
+    data = m.CircuitData.build(gpu_ctx, circ)
+    got = data.prove(wires, pis)
+    assert _first_mismatch(m, params, got, want) is None, name + ": " + _first_mismatch(m, params, got, want)
+    data.verify(got, pis)
+    data.close()
+    oc.close()
