@@ -17,7 +17,7 @@ import numpy as np
 
 from . import gl_np as gl
 
-OP_ADD, OP_SUB, OP_MUL, OP_EMIT = 0, 1, 2, 3
+OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_XOR, OP_DBLADD, OP_EMITBOOL, OP_MULADD = 0, 1, 2, 3, 4, 5, 6, 7
 K_REG, K_WIRE, K_CONST, K_IMM, K_PI = 0, 1, 2, 3, 4
 UNUSED_SELECTOR = 0xFFFFFFFF
 MAX_REGS = 64
@@ -84,8 +84,26 @@ class GateAsm:
     def mul(self, a, b):
         return self._op(OP_MUL, a, b)
 
+    def xor(self, a, b):
+        """a + b - 2ab (a ^ b on bits)"""
+        return self._op(OP_XOR, a, b)
+
+    def dbladd(self, a, b):
+        """2a + b (one Horner step of a bit recomposition)"""
+        return self._op(OP_DBLADD, a, b)
+
+    def muladd(self, acc, a, b):
+        """acc <- acc + a * b; acc must be a register operand"""
+        assert acc[0] == K_REG
+        return self._op(OP_MULADD, a, b, dst=acc[1])
+
     def emit(self, a):
         self.words += [OP_EMIT | a[0] << 16, a[1]]
+        self.num_constraints += 1
+
+    def emit_bool(self, a):
+        """constraint a * a - a"""
+        self.words += [OP_EMITBOOL | a[0] << 16, a[1]]
         self.num_constraints += 1
 
 

@@ -201,14 +201,23 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
       const u32 w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
       const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
       u64 x = q_operand(a, ka, ia, lds, T, tid, i);
-      if (op == 3) {
+      if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
+        if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
 #pragma unroll
         for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
           if (c < CH) acc[c] = gl_add(gl_mul(acc[c], a.alphas[c]), x);
         continue;
       }
       u64 y = q_operand(a, kb, ib, lds, T, tid, i);
-      u64 r = op == 0 ? gl_add(x, y) : op == 1 ? gl_sub(x, y) : gl_mul(x, y);
+      u64 r;
+      switch (op) {  // uniform across the wave: the code stream is the same for every point
+        case LCP2_OP_ADD: r = gl_add(x, y); break;
+        case LCP2_OP_SUB: r = gl_sub(x, y); break;
+        case LCP2_OP_MUL: r = gl_mul(x, y); break;
+        case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
+        case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
+        default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
+      }
       lds[dst * T + tid] = r;
     }
     u64 s = a.consts[(u64)G.selector_index * a.N + i];

@@ -85,6 +85,29 @@ void ext_pow_tables(gl2 z, u32 h, u64 hi_count, std::vector<u64> &out, size_t &l
 }  // namespace
 
 // ------------------------------------------------------------------ build()
+// validate the programs once so that neither the kernels nor the host verifier ever index out of range
+static const char *validate_programs(const lcp2_circuit_desc *d) {
+  const lcp2_params &p = d->params;
+  if (d->num_regs > 64 || d->num_selectors > p.num_constants) return "bad gate set";
+  for (u32 g = 0; g < d->num_gates; g++) {
+    const lcp2_gate &G = d->gates[g];
+    if (G.selector_index >= d->num_selectors || (size_t)(G.code_offset + G.code_len) * 2 > d->code_words || G.group_end < G.group_start)
+      return "gate descriptor out of range";
+    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
+      u32 w0 = d->code[2 * pc], w1 = d->code[2 * pc + 1];
+      u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, kk[2] = {(w0 >> 16) & 0xF, (w0 >> 20) & 0xF}, ii[2] = {w1 & 0xFFFF, w1 >> 16};
+      const bool emits = op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL;
+      if (op > LCP2_OP_MULADD || (!emits && dst >= std::max(d->num_regs, 1u))) return "bad instruction";
+      for (int s = 0; s < (emits ? 1 : 2); s++) {
+        u32 lim = kk[s] == 0 ? std::max(d->num_regs, 1u) : kk[s] == 1 ? p.num_wires : kk[s] == 2 ? p.num_constants - d->num_selectors
+                  : kk[s] == 3 ? (u32)d->num_imm : kk[s] == 4 ? d->num_public_inputs : 0;
+        if (ii[s] >= lim) return "operand out of range";
+      }
+    }
+  }
+  return nullptr;
+}
+
 extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lcp2_circuit **out) {
   if (!ctx || !d || !out) return LCP2_E_INVALID;
   *out = nullptr;
@@ -93,22 +116,7 @@ extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lc
   const lcp2_params &p = d->params;
   if (d->num_selectors > p.num_constants || d->num_regs > 64 || d->num_gates == 0) return ctx->fail(LCP2_E_INVALID, "bad gate set");
   if (d->num_public_inputs > 4096) return ctx->fail(LCP2_E_UNSUPPORTED, "too many public inputs");
-  // validate the programs once so that the kernels never index out of range
-  for (u32 g = 0; g < d->num_gates; g++) {
-    const lcp2_gate &G = d->gates[g];
-    if (G.selector_index >= d->num_selectors || (size_t)(G.code_offset + G.code_len) * 2 > d->code_words || G.group_end < G.group_start)
-      return ctx->fail(LCP2_E_INVALID, "gate descriptor out of range");
-    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
-      u32 w0 = d->code[2 * pc], w1 = d->code[2 * pc + 1];
-      u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, kk[2] = {(w0 >> 16) & 0xF, (w0 >> 20) & 0xF}, ii[2] = {w1 & 0xFFFF, w1 >> 16};
-      if (op > 3 || (op != 3 && dst >= std::max(d->num_regs, 1u))) return ctx->fail(LCP2_E_INVALID, "bad instruction");
-      for (int s = 0; s < (op == 3 ? 1 : 2); s++) {
-        u32 lim = kk[s] == 0 ? std::max(d->num_regs, 1u) : kk[s] == 1 ? p.num_wires : kk[s] == 2 ? p.num_constants - d->num_selectors
-                  : kk[s] == 3 ? (u32)d->num_imm : kk[s] == 4 ? d->num_public_inputs : 0;
-        if (ii[s] >= lim) return ctx->fail(LCP2_E_INVALID, "operand out of range");
-      }
-    }
-  }
+  if (const char *why = validate_programs(d)) return ctx->fail(LCP2_E_INVALID, why);
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<lcp2_circuit> c(new lcp2_circuit());
   c->ctx = ctx; c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
@@ -206,8 +214,7 @@ extern "C" int lcp2_verifier_create(const lcp2_circuit_desc *d, const uint64_t d
   if (p.num_challenges < 1 || p.num_challenges > 4 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS || p.num_query_rounds > 64 ||
       p.num_routed_wires > p.num_wires || d->num_selectors > p.num_constants)
     return LCP2_E_INVALID;
-  for (u32 g = 0; g < d->num_gates; g++)
-    if ((size_t)(d->gates[g].code_offset + d->gates[g].code_len) * 2 > d->code_words) return LCP2_E_INVALID;
+  if (validate_programs(d)) return LCP2_E_INVALID;
   lcp2_circuit *c = new lcp2_circuit();
   c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
   c->gates.assign(d->gates, d->gates + d->num_gates);

@@ -37,12 +37,20 @@ void eval_gates_ext(const VerifierView &v, const gl2 *wires, const gl2 *consts, 
         }
       };
       gl2 a = fetch(ka, ia);
-      if (op == 3) {
+      if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
+        if (op == LCP2_OP_EMITBOOL) a = gl2_sub(gl2_mul(a, a), a);
         for (u32 k = 0; k < CH; k++) acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
         continue;
       }
       gl2 b = fetch(kb, ib);
-      regs[dst] = op == 0 ? gl2_add(a, b) : op == 1 ? gl2_sub(a, b) : gl2_mul(a, b);
+      switch (op) {
+        case LCP2_OP_ADD: regs[dst] = gl2_add(a, b); break;
+        case LCP2_OP_SUB: regs[dst] = gl2_sub(a, b); break;
+        case LCP2_OP_MUL: regs[dst] = gl2_mul(a, b); break;
+        case LCP2_OP_XOR: { gl2 ab = gl2_mul(a, b); regs[dst] = gl2_sub(gl2_sub(gl2_add(a, b), ab), ab); break; }
+        case LCP2_OP_DBLADD: regs[dst] = gl2_add(gl2_add(a, a), b); break;
+        default: regs[dst] = gl2_add(regs[dst], gl2_mul(a, b)); break;  // LCP2_OP_MULADD
+      }
     }
     gl2 s = consts[G.selector_index], f = base2(1);
     for (u32 j = G.group_start; j < G.group_end; j++)

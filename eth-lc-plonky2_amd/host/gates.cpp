@@ -22,7 +22,8 @@ const char *gate_name(uint32_t k) {
 const uint32_t GATE_DEGREE[G_COUNT] = {0, 1, 1, 2, 3, 3, 3, 3};
 
 namespace {
-enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_EMIT = 3 };
+enum { OP_ADD = LCP2_OP_ADD, OP_SUB = LCP2_OP_SUB, OP_MUL = LCP2_OP_MUL, OP_EMIT = LCP2_OP_EMIT, OP_XOR = LCP2_OP_XOR, OP_DBLADD = LCP2_OP_DBLADD,
+       OP_EMITBOOL = LCP2_OP_EMITBOOL, OP_MULADD = LCP2_OP_MULADD };
 enum { K_REG = 0, K_WIRE = 1, K_CONST = 2, K_IMM = 3, K_PI = 4 };
 struct Opnd { uint32_t kind, idx; };
 inline Opnd R(uint32_t i) { return {K_REG, i}; }
@@ -52,32 +53,27 @@ struct Asm {
   void add(uint32_t d, Opnd a, Opnd b) { op(OP_ADD, d, a, b); }
   void sub(uint32_t d, Opnd a, Opnd b) { op(OP_SUB, d, a, b); }
   void mul(uint32_t d, Opnd a, Opnd b) { op(OP_MUL, d, a, b); }
+  void xor_(uint32_t d, Opnd a, Opnd b) { op(OP_XOR, d, a, b); }        // bits: a ^ b = a + b - 2ab
+  void dbladd(uint32_t d, Opnd a, Opnd b) { op(OP_DBLADD, d, a, b); }   // 2a + b: one Horner step of a bit recomposition
+  void muladd(uint32_t d, Opnd a, Opnd b) { op(OP_MULADD, d, a, b); }   // r[d] += a * b
   void emit(Opnd a) { cur->push_back(OP_EMIT | a.kind << 16); cur->push_back(a.idx); nconstraints++; }
+  void emit_bool(Opnd a) { cur->push_back(OP_EMITBOOL | a.kind << 16); cur->push_back(a.idx); nconstraints++; }
   void finish() {
     for (size_t k = blocks.size(); k-- > 0;) code.insert(code.end(), blocks[k].begin(), blocks[k].end());
   }
   // ---- constraint helpers (each is one constraint block)
-  void boolean(uint32_t wire) { begin(); mul(0, W(wire), W(wire)); sub(0, R(0), W(wire)); emit(R(0)); }
+  void boolean(uint32_t wire) { begin(); emit_bool(W(wire)); }
   void recompose(uint32_t bits, uint32_t word) {  // sum 2^i bit_i - word
     begin();
-    add(0, W(bits + 31), W(bits + 31));
-    add(0, R(0), W(bits + 30));
-    for (int i = 29; i >= 0; i--) { add(0, R(0), R(0)); add(0, R(0), W(bits + i)); }
+    dbladd(0, W(bits + 31), W(bits + 30));
+    for (int i = 29; i >= 0; i--) dbladd(0, R(0), W(bits + i));
     sub(0, R(0), W(word));
     emit(R(0));
   }
   // r[dst] = x ^ y ^ z for bits (z may be absent: z_wire < 0)
-  void xor3(uint32_t dst, uint32_t t, int x, int y, int z) {
-    mul(t, W(x), W(y));
-    add(dst, W(x), W(y));
-    sub(dst, R(dst), R(t));
-    sub(dst, R(dst), R(t));
-    if (z >= 0) {
-      mul(t, R(dst), W(z));
-      add(dst, R(dst), W(z));
-      sub(dst, R(dst), R(t));
-      sub(dst, R(dst), R(t));
-    }
+  void xor3(uint32_t dst, uint32_t, int x, int y, int z) {
+    xor_(dst, W(x), W(y));
+    if (z >= 0) xor_(dst, R(dst), W(z));
   }
 };
 
@@ -117,9 +113,8 @@ void prog_sha_add(Asm &a) {
 }
 // tail of a sum equation: acc(r1) + extras - out - 2^32 * (c0 + 2 c1 [+ 4 c2])
 void carry_tail(Asm &a, uint32_t carry0, int ncarry) {
-  a.add(2, W(carry0 + ncarry - 1), W(carry0 + ncarry - 1));
-  for (int k = ncarry - 2; k >= 1; k--) { a.add(2, R(2), W(carry0 + k)); a.add(2, R(2), R(2)); }
-  a.add(2, R(2), W(carry0));
+  a.dbladd(2, W(carry0 + ncarry - 1), W(carry0 + ncarry - 2));
+  for (int k = ncarry - 3; k >= 0; k--) a.dbladd(2, R(2), W(carry0 + k));
   a.mul(2, R(2), a.IMM(TWO32));
   a.sub(1, R(1), R(2));
   a.emit(R(1));
@@ -134,11 +129,10 @@ void prog_sha_round_e(Asm &a) {
   for (int i = 31; i >= 0; i--) {
     a.xor3(3, 4, be + (i + 6) % 32, be + (i + 11) % 32, be + (i + 25) % 32);  // S1(e) bit i
     a.sub(5, W(bf + i), W(bg + i));
-    a.mul(5, R(5), W(be + i));
-    a.add(5, R(5), W(bg + i));  // Ch bit i
-    a.add(3, R(3), R(5));
+    a.muladd(3, R(5), W(be + i));
+    a.add(3, R(3), W(bg + i));  // + Ch bit i = g + e (f - g)
     if (i == 31) a.add(1, R(3), a.IMM(0));
-    else { a.add(1, R(1), R(1)); a.add(1, R(1), R(3)); }
+    else a.dbladd(1, R(1), R(3));
   }
   a.add(1, R(1), W(h)); a.add(1, R(1), C(0)); a.add(1, R(1), W(w)); a.sub(1, R(1), W(t1));
   carry_tail(a, c0, 3);
@@ -160,15 +154,11 @@ void prog_sha_round_a(Asm &a) {
   a.begin();
   for (int i = 31; i >= 0; i--) {
     a.xor3(3, 4, ba + (i + 2) % 32, ba + (i + 13) % 32, ba + (i + 22) % 32);  // S0(a) bit i
-    a.mul(4, W(ba + i), W(bb + i));      // ab
-    a.add(5, W(ba + i), W(bb + i));
-    a.sub(5, R(5), R(4));
-    a.sub(5, R(5), R(4));                // a ^ b
-    a.mul(5, R(5), W(bc + i));
-    a.add(5, R(5), R(4));                // Maj = ab + c (a ^ b)
-    a.add(3, R(3), R(5));
+    a.muladd(3, W(ba + i), W(bb + i));   // + ab
+    a.xor_(5, W(ba + i), W(bb + i));     // a ^ b
+    a.muladd(3, R(5), W(bc + i));        // + c (a ^ b): Maj = ab + c (a ^ b)
     if (i == 31) a.add(1, R(3), a.IMM(0));
-    else { a.add(1, R(1), R(1)); a.add(1, R(1), R(3)); }
+    else a.dbladd(1, R(1), R(3));
   }
   a.add(1, R(1), W(t1)); a.sub(1, R(1), W(a_new));
   carry_tail(a, c0, 2);
@@ -185,7 +175,7 @@ void prog_sha_sched(Asm &a) {
     a.xor3(5, 4, b2 + (i + 17) % 32, b2 + (i + 19) % 32, i + 10 < 32 ? (int)(b2 + i + 10) : -1);   // s1(w2) bit i
     a.add(3, R(3), R(5));
     if (i == 31) a.add(1, R(3), a.IMM(0));
-    else { a.add(1, R(1), R(1)); a.add(1, R(1), R(3)); }
+    else a.dbladd(1, R(1), R(3));
   }
   a.add(1, R(1), W(w7)); a.add(1, R(1), W(w16)); a.sub(1, R(1), W(wt));
   carry_tail(a, c0, 2);

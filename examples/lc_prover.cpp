@@ -73,7 +73,9 @@ int main(int argc, char **argv) {
     t0 = std::chrono::steady_clock::now();
     data->attach_gpu(ctx);
     printf("constants/sigmas committed on the GPU in %.1f ms\n", ms_since(t0));
+    const bool prof = getenv("LCP2_PROF") != nullptr;  // HIP-event time per kernel family of the last proof
     for (int k = 0; k < repeat; k++) {
+      if (prof && k == repeat - 1) { lcp2_prof_enable(ctx, 1); lcp2_prof_reset(ctx); }
       t0 = std::chrono::steady_clock::now();
       ProofWithPublicInputs proof = data->prove(pw);
       const double prove_ms = ms_since(t0);
@@ -81,6 +83,18 @@ int main(int argc, char **argv) {
       data->verify(proof);
       printf("proof %d: proved in %.1f ms (witness generation included), verified in %.1f ms, %zu proof words, %zu public inputs\n", k, prove_ms,
              ms_since(t0), proof.proof.size(), proof.public_inputs.size());
+    }
+    if (prof) {
+      static const char *names[LCP2_K_COUNT] = {"intt", "lde", "leaf_hash", "merkle", "perm_z", "quotient", "openings", "fri", "pow", "sha256_witness", "other"};
+      double sum = 0;
+      for (int f = 0; f < LCP2_K_COUNT; f++) {
+        double ms = 0, bytes = 0;
+        uint64_t launches = 0;
+        lcp2_prof_get(ctx, f, &ms, &launches, &bytes);
+        sum += ms;
+        if (launches) printf("  %-15s %8.3f ms  (%llu scopes)\n", names[f], ms, (unsigned long long)launches);
+      }
+      printf("  %-15s %8.3f ms\n", "sum of kernels", sum);
     }
     data.reset();
     lcp2_ctx_destroy(ctx);

@@ -188,12 +188,15 @@ int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs /* nullable */, uint64_t *
  * verifier interpret:
  *     instruction = 2 words:  w0 = op | dst << 8 | kind_a << 16 | kind_b << 20,  w1 = idx_a | idx_b << 16
  *     op   0 ADD  1 SUB  2 MUL (dst <- a op b)   3 EMIT (acc <- acc * alpha + a)
+ *          4 XOR (dst <- a + b - 2ab)  5 DBLADD (dst <- 2a + b)  6 EMITBOOL (EMIT of a*a - a)  7 MULADD (dst <- dst + a*b)
  *     kind 0 REG  1 WIRE (local wire)  2 CONST (gate constant, after the selector columns)
  *          3 IMM (imm[idx])  4 PI (public_inputs[idx])
  * A gate lists its constraints from the LAST to the FIRST (EMIT is a Horner step).
  * Selectors follow plonky2 gates/selectors.rs: gate g is active on rows where
  * constants[selector_index] == selector_value; its filter is
  *     prod_{j in [group_start, group_end), j != selector_value} (j - s) * (num_selectors > 1 ? (2^32 - 1 - s) : 1). */
+enum { LCP2_OP_ADD = 0, LCP2_OP_SUB = 1, LCP2_OP_MUL = 2, LCP2_OP_EMIT = 3, LCP2_OP_XOR = 4, LCP2_OP_DBLADD = 5,
+       LCP2_OP_EMITBOOL = 6, LCP2_OP_MULADD = 7 };
 typedef struct {
   uint32_t selector_index, selector_value, group_start, group_end;
   uint32_t code_offset, code_len; /* in instructions */

@@ -243,14 +243,22 @@ static void eval_gates_base(const orc_circuit *c, const uint64_t *wires, const u
     for (uint32_t pc = G->code_offset; pc < G->code_offset + G->code_len; pc++) {
       DECODE(c->code, pc);
       uint64_t a = operand_b(c, ka, ia, regs, wires, consts, pis);
-      if (op == ORC_OP_EMIT) {
+      if (op == ORC_OP_EMIT || op == ORC_OP_EMITBOOL) {
+        if (op == ORC_OP_EMITBOOL) a = gl_sub(gl_mul(a, a), a);
         for (uint32_t k = 0; k < CH; k++) acc[k] = gl_add(gl_mul(acc[k], alphas[k]), a);
         if (raw && (int)g == raw_gate) raw[G->num_constraints - 1 - emitted] = a;
         emitted++;
         continue;
       }
       uint64_t b = operand_b(c, kb, ib, regs, wires, consts, pis);
-      regs[dst] = op == ORC_OP_ADD ? gl_add(a, b) : op == ORC_OP_SUB ? gl_sub(a, b) : gl_mul(a, b);
+      switch (op) {
+        case ORC_OP_ADD: regs[dst] = gl_add(a, b); break;
+        case ORC_OP_SUB: regs[dst] = gl_sub(a, b); break;
+        case ORC_OP_MUL: regs[dst] = gl_mul(a, b); break;
+        case ORC_OP_XOR: { uint64_t ab = gl_mul(a, b); regs[dst] = gl_sub(gl_sub(gl_add(a, b), ab), ab); break; }
+        case ORC_OP_DBLADD: regs[dst] = gl_add(gl_add(a, a), b); break;
+        default: regs[dst] = gl_add(regs[dst], gl_mul(a, b)); break; /* ORC_OP_MULADD */
+      }
     }
     uint64_t f = filter_b(c, G, consts);
     for (uint32_t k = 0; k < CH; k++) out[k] = gl_add(out[k], gl_mul(f, acc[k]));
@@ -279,12 +287,20 @@ static void eval_gates_ext(const orc_circuit *c, const gl2_t *wires, const gl2_t
     for (uint32_t pc = G->code_offset; pc < G->code_offset + G->code_len; pc++) {
       DECODE(c->code, pc);
       gl2_t a = operand_e(c, ka, ia, regs, wires, consts, pis);
-      if (op == ORC_OP_EMIT) {
+      if (op == ORC_OP_EMIT || op == ORC_OP_EMITBOOL) {
+        if (op == ORC_OP_EMITBOOL) a = gl2_sub(gl2_mul(a, a), a);
         for (uint32_t k = 0; k < CH; k++) acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
         continue;
       }
       gl2_t b = operand_e(c, kb, ib, regs, wires, consts, pis);
-      regs[dst] = op == ORC_OP_ADD ? gl2_add(a, b) : op == ORC_OP_SUB ? gl2_sub(a, b) : gl2_mul(a, b);
+      switch (op) {
+        case ORC_OP_ADD: regs[dst] = gl2_add(a, b); break;
+        case ORC_OP_SUB: regs[dst] = gl2_sub(a, b); break;
+        case ORC_OP_MUL: regs[dst] = gl2_mul(a, b); break;
+        case ORC_OP_XOR: { gl2_t ab = gl2_mul(a, b); regs[dst] = gl2_sub(gl2_sub(gl2_add(a, b), ab), ab); break; }
+        case ORC_OP_DBLADD: regs[dst] = gl2_add(gl2_add(a, a), b); break;
+        default: regs[dst] = gl2_add(regs[dst], gl2_mul(a, b)); break; /* ORC_OP_MULADD */
+      }
     }
     gl2_t s = consts[G->selector_index], f = gl2_from_base(1);
     for (uint32_t j = G->group_start; j < G->group_end; j++)

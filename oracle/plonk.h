@@ -26,7 +26,11 @@ typedef struct {
 } orc_gate;
 
 /* gate program instruction: word0 = op | dst << 8 | kind_a << 16 | kind_b << 20 ; word1 = idx_a | idx_b << 16 */
-enum { ORC_OP_ADD = 0, ORC_OP_SUB = 1, ORC_OP_MUL = 2, ORC_OP_EMIT = 3 };
+enum { ORC_OP_ADD = 0, ORC_OP_SUB = 1, ORC_OP_MUL = 2, ORC_OP_EMIT = 3,
+       ORC_OP_XOR = 4,      /* dst = a + b - 2ab */
+       ORC_OP_DBLADD = 5,   /* dst = 2a + b */
+       ORC_OP_EMITBOOL = 6, /* emits a*a - a */
+       ORC_OP_MULADD = 7 }; /* dst = dst + a*b */
 enum { ORC_K_REG = 0, ORC_K_WIRE = 1, ORC_K_CONST = 2, ORC_K_IMM = 3, ORC_K_PI = 4 };
 #define ORC_MAX_REGS 64
 #define ORC_UNUSED_SELECTOR 0xFFFFFFFFull

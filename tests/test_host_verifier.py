@@ -57,3 +57,28 @@ def test_small_value_witness(oracle):
     oc = oracle_lib.OracleCircuit(oracle, circ)
     assert oc.check_witness(wires, pis)[0] == 0
     assert oc.verify(oc.prove(wires, pis), pis) == 0
+
+
+def test_verifier_create_validates_gate_programs(oracle):
+    """lcp2_verifier_create checks every instruction (opcode, register, operand ranges) like lcp2_circuit_create does,
+    so that a hostile circuit description cannot make the host interpreter index out of range."""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(5, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    digest, cap = oc.digest()
+    code = circ.gateset.code
+    first = next(g for g in circ.gateset.gates if g.code_len).code_offset
+    saved = (int(code[2 * first]), int(code[2 * first + 1]))
+    try:
+        for w0, w1 in [((saved[0] & ~0xF) | 9, saved[1]),                    # unknown opcode
+                       ((saved[0] & ~0xFF00) | (200 << 8), saved[1]),         # destination register out of range
+                       ((saved[0] & ~0xF0000) | (1 << 16), 0xFFFF)]:          # wire operand out of range
+            code[2 * first], code[2 * first + 1] = w0, w1
+            with pytest.raises(m.Lcp2Error) as e:
+                m.CircuitData.verifier_only(circ, digest, cap)
+            assert e.value.status == -1
+    finally:
+        code[2 * first], code[2 * first + 1] = saved
+    m.CircuitData.verifier_only(circ, digest, cap).close()
+    oc.close()
