@@ -6,7 +6,10 @@
 //  k_merkle_level            PoseidonHash::two_to_one per node
 //  k_sha256_level            two_to_one_sha256 (reference src/merkle_tree_gadget.rs:28-40)
 //
-// One permutation per lane: the 12-element state is 24 VGPRs, round constants
+//  k_merkle_level_coop / k_hash_ext_leaves_coop   the same two for levels of <= 4096 nodes, one 16-lane group per
+//                            permutation with wavefront shuffles for the MDS layer (latency instead of throughput)
+//
+// One permutation per lane everywhere else: the 12-element state is 24 VGPRs, round constants
 // are wave-uniform scalar loads, and the LDE matrix is column-major so that the
 // lanes of a wave read 512 consecutive bytes of each column (no transpose pass,
 // K3 of the survey is fused away).  These kernels are integer-ALU bound.
@@ -94,6 +97,42 @@ __global__ __launch_bounds__(HASH_THREADS) void k_merkle_level(const u64 *__rest
   ulonglong2 *d = (ulonglong2 *)(parents + 4 * i);
   d[0] = make_ulonglong2(s[0], s[1]);
   d[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// ---- latency-bound sizes: one 16-lane group per permutation (poseidon.hpp: pos_permute_coop)
+constexpr int COOP_THREADS = 256;
+__device__ __forceinline__ void coop_load_rc(u64 *rcs, const u64 *__restrict__ rc) {
+  for (u32 i = threadIdx.x; i < POS_ROUNDS * POS_W; i += COOP_THREADS) rcs[i] = rc[i];
+  __syncthreads();
+}
+__global__ __launch_bounds__(COOP_THREADS) void k_merkle_level_coop(const u64 *__restrict__ children, u64 *__restrict__ parents,
+                                                                      u64 nparents, const u64 *__restrict__ rc) {
+  __shared__ u64 rcs[POS_ROUNDS * POS_W];
+  coop_load_rc(rcs, rc);
+  const u64 t = (u64)blockIdx.x * COOP_THREADS + threadIdx.x, node = t >> 4;
+  const u32 j = (u32)t & 15;
+  const bool live = node < nparents;  // every lane runs the shuffles; dead groups recompute node 0
+  const u64 nd = live ? node : 0;
+  const u64 v = j < 8 ? children[8 * nd + j] : 0;
+  const u64 r = pos_permute_coop(v, j, rcs);
+  if (live && j < 4) parents[4 * nd + j] = r;
+}
+// FRI layer leaves of 2 * arity > 4 elements: absorb 8 at a time (overwrite mode)
+__global__ __launch_bounds__(COOP_THREADS) void k_hash_ext_leaves_coop(const u64 *__restrict__ p0, const u64 *__restrict__ p1, u32 arity,
+                                                                         u64 nleaves, u64 *__restrict__ digests, const u64 *__restrict__ rc) {
+  __shared__ u64 rcs[POS_ROUNDS * POS_W];
+  coop_load_rc(rcs, rc);
+  const u64 t = (u64)blockIdx.x * COOP_THREADS + threadIdx.x, leaf = t >> 4;
+  const u32 j = (u32)t & 15;
+  const bool live = leaf < nleaves;
+  const u64 lf = live ? leaf : 0;
+  const u64 *src = ((j & 1) ? p1 : p0) + lf * arity + (j >> 1);
+  u64 v = 0;
+  for (u32 e0 = 0; e0 < arity; e0 += 4) {
+    if (j < 8 && e0 + (j >> 1) < arity) v = src[e0];
+    v = pos_permute_coop(v, j, rcs);
+  }
+  if (live && j < 4) digests[4 * lf + j] = v;
 }
 
 // ------------------------------------------------------------------ SHA-256
@@ -196,10 +235,18 @@ void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col
                      leaf_len, nleaves, digests, rc);
 }
 void launch_hash_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, u64 nleaves, u64 *digests, const u64 *rc) {
+  if (nleaves <= POS_COOP_MAX_NODES && 2 * arity > 4) {
+    hipLaunchKernelGGL(k_hash_ext_leaves_coop, dim3(blocks_for(nleaves * 16, COOP_THREADS)), dim3(COOP_THREADS), 0, s, p0, p1, arity, nleaves, digests, rc);
+    return;
+  }
   hipLaunchKernelGGL(k_hash_ext_leaves, dim3(blocks_for(nleaves, HASH_THREADS)), dim3(HASH_THREADS), 0, s, p0, p1, arity, nleaves,
                      digests, rc);
 }
 void launch_merkle_level(hipStream_t s, const u64 *children, u64 *parents, u64 nparents, const u64 *rc) {
+  if (nparents <= POS_COOP_MAX_NODES) {
+    hipLaunchKernelGGL(k_merkle_level_coop, dim3(blocks_for(nparents * 16, COOP_THREADS)), dim3(COOP_THREADS), 0, s, children, parents, nparents, rc);
+    return;
+  }
   hipLaunchKernelGGL(k_merkle_level, dim3(blocks_for(nparents, HASH_THREADS)), dim3(HASH_THREADS), 0, s, children, parents, nparents, rc);
 }
 void launch_sha256_level(hipStream_t s, const uint8_t *children, uint8_t *parents, u64 nparents, u64 trees, u64 child_tree_stride,
