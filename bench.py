@@ -30,15 +30,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench
 
 
-def pmc_traffic_bytes(kernel):
+def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC passes (counters cannot be read from inside the process):
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, same launch population as the in-process average."""
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) / algorithmic bytes, both per launch of the PMC pass,
+    applied to the algorithmic bytes per launch of THIS run (the passes ran 1 proof, a default run averages 7)."""
     try:
         k = json.load(open(PMC_TRAFFIC))["kernels"][kernel]
-        return (k["read_GB_per_launch_corrected"] + k["write_GB_per_launch"]) * 1e9
+        return k["traffic_over_algorithmic"] * algorithmic_bytes_per_launch
     except (OSError, KeyError, ValueError):
         return None
 
@@ -163,7 +164,7 @@ def main():
                        "degree_bits": a.degree_bits, "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
                        "parallelism": "replicas x%d (one independent proof per GPU)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves", lh["bytes"] / max(lh["launches"], 1)),
                          "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
                          "note": "integer-ALU bound (Poseidon): see DESIGN.md; HBM fraction is legitimately low"},
             "kernels": kern,
