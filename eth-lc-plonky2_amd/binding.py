@@ -103,6 +103,8 @@ def load_library():
         "lcp2_buffer_free": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_buffer_zero": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_buffer_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
+        "lcp2_buffer_write": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
+        "lcp2_buffer_copy": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_commit_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_commit_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_commit_cosets": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
@@ -119,6 +121,15 @@ def load_library():
         "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_fri_open": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
+        "lcp2_challenger_init": (None, [c.POINTER(ChallengerState)]),
+        "lcp2_challenger_observe": (c.c_int, [c.POINTER(ChallengerState), c.c_void_p, c.c_size_t]),
+        "lcp2_challenger_get": (c.c_int, [c.POINTER(ChallengerState), c.c_void_p, c.c_size_t]),
+        "lcp2_hash_no_pad": (c.c_int, [c.c_void_p, c.c_size_t, c.c_void_p]),
+        "lcp2_circuit_create_sharded": (c.c_int, [c.c_void_p, c.POINTER(CircuitDesc), c.c_uint32, c.c_uint32, c.POINTER(c.c_void_p)]),
+        "lcp2_circuit_set_constants_cap": (c.c_int, [c.c_void_p, c.c_void_p]),
+        "lcp2_quotient_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_quotient_buffer": (c.c_int, [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]),
+        "lcp2_quotient_commit": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(c.c_int)]),
         "lcp2_last_challenges": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
@@ -298,6 +309,18 @@ class Context:
         return o
 
     # ---- timing
+    def buffer_read(self, dev_ptr, words):
+        out = np.zeros(words, dtype=np.uint64)
+        self._check(self.lib.lcp2_buffer_read(self.handle, _ptr(out), ctypes.c_void_p(dev_ptr), words * 8))
+        return out
+
+    def buffer_write(self, dev_ptr, arr):
+        a = _np_u64(arr)
+        self._check(self.lib.lcp2_buffer_write(self.handle, ctypes.c_void_p(dev_ptr), _ptr(a), a.size * 8))
+
+    def buffer_copy(self, dst_ptr, src_ptr, words):
+        self._check(self.lib.lcp2_buffer_copy(self.handle, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), words * 8))
+
     def prof_enable(self, on=True):
         self._check(self.lib.lcp2_prof_enable(self.handle, int(on)))
 
@@ -311,6 +334,40 @@ class Context:
             self._check(self.lib.lcp2_prof_get(self.handle, i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
             out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
         return out
+
+
+class Challenger:
+    """plonky2's Challenger<F, PoseidonHash> on the host (lcp2_challenger_*): the transcript of a caller that drives the
+    seams of data.prove() itself (staged or sharded proving)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.state = ChallengerState()
+        self.lib.lcp2_challenger_init(ctypes.byref(self.state))
+
+    def observe(self, values):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64).ravel())
+        rc = self.lib.lcp2_challenger_observe(ctypes.byref(self.state), _ptr(v), v.size)
+        if rc:
+            raise Lcp2Error(rc, self.lib.lcp2_status_str(rc).decode())
+
+    def get(self, count=1):
+        out = np.zeros(count, dtype=np.uint64)
+        rc = self.lib.lcp2_challenger_get(ctypes.byref(self.state), _ptr(out), count)
+        if rc:
+            raise Lcp2Error(rc, self.lib.lcp2_status_str(rc).decode())
+        return out
+
+
+def hash_no_pad(values):
+    """PoseidonHash::hash_no_pad on the host (public-input hash of the transcript)"""
+    lib = load_library()
+    v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64).ravel())
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib.lcp2_hash_no_pad(_ptr(v) if v.size else None, v.size, _ptr(out))
+    if rc:
+        raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+    return out
 
 
 class ProofRejected(Lcp2Error):
@@ -353,6 +410,34 @@ class CircuitData:
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.lcp2_circuit_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
         return cls(ctx, circ, h, keep)
+
+    @classmethod
+    def build_sharded(cls, ctx, circ, block_first, block_count, constants_sigmas_ptr=None, mem=MEM_HOST):
+        """one rank's part of a coset-sharded circuit: holds the leaf blocks [block_first, block_first + block_count).
+        The digest is valid after set_constants_cap(OR of every rank's digest()[1])."""
+        d, keep = _describe(circ, constants_sigmas_ptr, mem)
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.lcp2_circuit_create_sharded(ctx.handle, ctypes.byref(d), block_first, block_count, ctypes.byref(h)))
+        return cls(ctx, circ, h, keep)
+
+    def set_constants_cap(self, cap):
+        cp = _np_u64(cap)
+        self._check(self.lib.lcp2_circuit_set_constants_cap(self.handle, _ptr(cp)))
+
+    def quotient_values(self, alphas, public_inputs):
+        a, pis = _np_u64(alphas), _np_u64(public_inputs)
+        self._check(self.lib.lcp2_quotient_values(self.handle, _ptr(a), _ptr(pis)))
+
+    def quotient_buffer(self):
+        """(device pointer, uint64 words) of the quotient values [num_challenges][8n]: the one bulk exchange of a sharded proof"""
+        ptr, words = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self.lib.lcp2_quotient_buffer(self.handle, ctypes.byref(ptr), ctypes.byref(words)))
+        return ptr.value, words.value
+
+    def quotient_commit(self):
+        cap = self._cap()
+        self._check(self.lib.lcp2_quotient_commit(self.handle, _ptr(cap)))
+        return cap
 
     @classmethod
     def verifier_only(cls, circ, digest, cap):

@@ -174,8 +174,8 @@ void launch_perm_finalize(hipStream_t s, const PermArgs &a) {
 __device__ __forceinline__ u64 q_operand(const QuotientArgs &a, u32 kind, u32 idx, const u64 *lds, u32 T, u32 tid, u64 i) {
   switch (kind) {
     case 0: return lds[idx * T + tid];
-    case 1: return a.wires[(u64)idx * a.N + i];
-    case 2: return a.consts[(u64)(a.num_selectors + idx) * a.N + i];
+    case 1: return a.wires[(u64)idx * a.stride + i];
+    case 2: return a.consts[(u64)(a.num_selectors + idx) * a.stride + i];
     case 3: return a.imm[idx];
     default: return a.pis[idx];
   }
@@ -184,8 +184,9 @@ __device__ __forceinline__ u64 q_operand(const QuotientArgs &a, u32 kind, u32 id
 __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
-  const u64 i = (u64)blockIdx.x * T + tid;  // storage (leaf) index
-  if (i >= a.N) return;                      // no barrier is used below
+  const u64 i = (u64)blockIdx.x * T + tid;  // local storage (leaf) index; global index = a.leaf0 + i
+  if (i >= a.count) return;                  // no barrier is used below
+  const u64 ig = a.leaf0 + i;
   const u32 CH = a.num_challenges;
   u64 res[QUOTIENT_MAX_CH];
 #pragma unroll
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
       }
       lds[dst * T + tid] = r;
     }
-    u64 s = a.consts[(u64)G.selector_index * a.N + i];
+    u64 s = a.consts[(u64)G.selector_index * a.stride + i];
     u64 f = 1;
     for (u32 j = G.group_start; j < G.group_end; j++)
       if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
   // ---- permutation argument terms, folded in front of the gate constraints:
   //   terms = [ L0 (Z_c - 1) ]_c ++ [ prev * prod num - next * prod den ]_{c,k} ; res <- sum_t alpha^t terms_t + alpha^nt * gates
   const u32 lgN = a.lgN;
-  const u64 jnat = bitrev32((u32)i, lgN);
-  const u64 x = two_level(a.points, jnat);  // 7 * w_N^bitrev(i)
-  const u64 inext = bitrev32((u32)((jnat + (1u << a.rate_bits)) & (a.N - 1)), lgN);
+  const u64 jnat = bitrev32((u32)ig, lgN);
+  const u64 x = two_level(a.points, jnat);  // 7 * w_N^bitrev(ig)
+  const u64 inext = bitrev32((u32)((jnat + (1u << a.rate_bits)) & (a.N - 1)), lgN) - a.leaf0;  // same coset = same leaf block
   const u32 npp = a.nchunks - 1;
   // Horner from the last term down to the first, for every alpha
   for (int c2 = (int)CH - 1; c2 >= 0; c2--) {
@@ -244,33 +245,33 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
     for (int k = (int)a.nchunks - 1; k >= 0; k--) {
       u64 pn = 1, pd = 1;
       for (u32 j = k * a.chunk; j < a.num_routed && j < (k + 1) * a.chunk; j++) {
-        u64 wg = gl_add(a.wires[(u64)j * a.N + i], gamma);
+        u64 wg = gl_add(a.wires[(u64)j * a.stride + i], gamma);
         pn = gl_mul(pn, gl_add(wg, gl_mul(bx, a.k_is[j])));
-        pd = gl_mul(pd, gl_add(wg, gl_mul(beta, a.consts[(u64)(a.num_constants + j) * a.N + i])));
+        pd = gl_mul(pd, gl_add(wg, gl_mul(beta, a.consts[(u64)(a.num_constants + j) * a.stride + i])));
       }
-      u64 prev = k == 0 ? a.zs[(u64)c2 * a.N + i] : a.zs[((u64)CH + (u64)c2 * npp + (k - 1)) * a.N + i];
-      u64 next = (u32)k < npp ? a.zs[((u64)CH + (u64)c2 * npp + k) * a.N + i] : a.zs[(u64)c2 * a.N + inext];
+      u64 prev = k == 0 ? a.zs[(u64)c2 * a.stride + i] : a.zs[((u64)CH + (u64)c2 * npp + (k - 1)) * a.stride + i];
+      u64 next = (u32)k < npp ? a.zs[((u64)CH + (u64)c2 * npp + k) * a.stride + i] : a.zs[(u64)c2 * a.stride + inext];
       u64 term = gl_sub(gl_mul(prev, pn), gl_mul(next, pd));
 #pragma unroll
       for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
         if (c < CH) res[c] = gl_add(gl_mul(res[c], a.alphas[c]), term);
     }
   }
-  const u64 l0 = a.l0[i];
+  const u64 l0 = a.l0[ig];
   for (int c2 = (int)CH - 1; c2 >= 0; c2--) {
-    u64 term = gl_mul(l0, gl_sub(a.zs[(u64)c2 * a.N + i], 1));
+    u64 term = gl_mul(l0, gl_sub(a.zs[(u64)c2 * a.stride + i], 1));
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
       if (c < CH) res[c] = gl_add(gl_mul(res[c], a.alphas[c]), term);
   }
-  const u64 zhi = a.zh_inv[i >> (lgN - a.rate_bits)];
+  const u64 zhi = a.zh_inv[ig >> (lgN - a.rate_bits)];
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-    if (c < CH) a.out[(u64)c * a.N + i] = gl_mul(res[c], zhi);
+    if (c < CH) a.out[(u64)c * a.N + ig] = gl_mul(res[c], zhi);
 }
 void launch_quotient(hipStream_t s, const QuotientArgs &a) {
   size_t lds = (size_t)a.num_regs * QUOTIENT_THREADS * sizeof(u64);
-  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((a.N + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a);
+  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a);
 }
 
 // ------------------------------------------------------------------ K7a: evaluate coefficient polynomials at an extension point

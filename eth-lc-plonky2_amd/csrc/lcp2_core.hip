@@ -564,6 +564,20 @@ extern "C" int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes) {
   LCP2_HIP(ctx, hipMemsetAsync(dev, 0, bytes, ctx->stream));
   return LCP2_OK;
 }
+extern "C" int lcp2_buffer_write(lcp2_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+  if (!ctx || !dev_dst || !host_src) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
+extern "C" int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_src, size_t bytes) {
+  if (!ctx || !dev_dst || !dev_src) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_HIP(ctx, hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
 extern "C" int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
   if (!ctx || !host_dst || !dev_src) return LCP2_E_INVALID;
   LCP2_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -36,6 +36,12 @@ struct lcp2_circuit {
   // staged proving (lcp2_commit_wires -> lcp2_perm_zs -> lcp2_quotient -> lcp2_fri_open)
   const u64 *d_wires_cur = nullptr;
   int stage = 0;
+  // coset-sharded circuit: this handle holds the leaf blocks [bf, bf + bc) of every LDE and Merkle tree;
+  // bc = 0: all of them.  cap_final: the full constants_sigmas cap (hence the digest) is known.
+  uint32_t bf = 0, bc = 0;
+  bool cap_final = true;
+  bool sharded() const { return bc != 0; }
+  uint32_t nblocks() const { return bc ? bc : (1u << p.rate_bits); }
 };
 
 namespace {
@@ -108,7 +114,17 @@ static const char *validate_programs(const lcp2_circuit_desc *d) {
   return nullptr;
 }
 
-extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lcp2_circuit **out) {
+// cap of oracle `o` into a full-size cap buffer: a sharded circuit writes its own entries at their global position and
+// zeros elsewhere (its share: the caps of all ranks OR-ed together are the cap)
+static int download_cap(lcp2_circuit *c, const lcp2_oracle &o, u64 *dst) {
+  const size_t capw = (size_t)4 << c->p.cap_height;
+  if (!c->sharded()) return download(c->ctx, dst, o.cap_dev(), capw * 8);
+  const size_t per_block = (size_t)4 << (c->p.cap_height - c->p.rate_bits);
+  memset(dst, 0, capw * 8);
+  return download(c->ctx, dst + c->bf * per_block, o.cap_dev(), per_block * c->bc * 8);
+}
+
+static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf, uint32_t bc, lcp2_circuit **out) {
   if (!ctx || !d || !out) return LCP2_E_INVALID;
   *out = nullptr;
   if (!d->constants_sigmas || !d->k_is || !d->gates || !d->code || (d->num_imm && !d->imm)) return ctx->fail(LCP2_E_INVALID, "null description field");
@@ -120,6 +136,12 @@ extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lc
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<lcp2_circuit> c(new lcp2_circuit());
   c->ctx = ctx; c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
+  if (bc) {
+    if (p.cap_height < p.rate_bits) return ctx->fail(LCP2_E_INVALID, "sharded circuit: needs cap_height >= rate_bits");
+    if ((bc & (bc - 1)) || bf % bc || bf + bc > (1u << p.rate_bits)) return ctx->fail(LCP2_E_INVALID, "sharded circuit: block range must be an aligned power of two");
+    c->bf = bf; c->bc = bc; c->cap_final = false;
+    for (lcp2_oracle *o : {&c->cs, &c->wires, &c->zs, &c->quot}) { o->block_first = bf; o->block_count = bc; }
+  }
   c->gates.assign(d->gates, d->gates + d->num_gates);
   c->code.assign(d->code, d->code + d->code_words);
   c->imm.resize(std::max<size_t>(d->num_imm, 1), 0);
@@ -139,8 +161,8 @@ extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lc
   LCP2_TRY(commit_values_dev(ctx, c->cs_values.u(), ncs, p.degree_bits, p.rate_bits, p.cap_height, &c->cs));
   const size_t capw = (size_t)4 << p.cap_height;
   c->cs_cap.resize(capw);
-  LCP2_TRY(download(ctx, c->cs_cap.data(), c->cs.cap_dev(), capw * 8));
-  {  // circuit digest = H(constants_sigmas_cap || degree_bits)
+  LCP2_TRY(download_cap(c.get(), c->cs, c->cs_cap.data()));
+  if (!c->sharded()) {  // circuit digest = H(constants_sigmas_cap || degree_bits); sharded: lcp2_circuit_set_constants_cap
     std::vector<u64> buf(c->cs_cap);
     buf.push_back(p.degree_bits);
     HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), c->digest);
@@ -204,6 +226,27 @@ extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lc
   LCP2_HIP(ctx, c->q_buf.alloc((size_t)64 * (ncs + p.num_wires + CH * (1 + npp) + CH * p.quotient_degree_factor + 4 * 4 * 32 + LCP2_MAX_FRI_LAYERS * (64 + 4 * 32)) * 8));
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = c.release();
+  return LCP2_OK;
+}
+
+extern "C" int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, lcp2_circuit **out) { return circuit_create(ctx, d, 0, 0, out); }
+extern "C" int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t block_first, uint32_t block_count,
+                                           lcp2_circuit **out) {
+  if (block_count == 0) return LCP2_E_INVALID;
+  return circuit_create(ctx, d, block_first, block_count, out);
+}
+extern "C" int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap) {
+  if (!c || !cap) return LCP2_E_INVALID;
+  if (!c->sharded()) return LCP2_E_INVALID;
+  const size_t capw = (size_t)4 << c->p.cap_height, per_block = (size_t)4 << (c->p.cap_height - c->p.rate_bits);
+  // the entries this handle computed itself must be in the cap it is given
+  if (memcmp(cap + c->bf * per_block, c->cs_cap.data() + c->bf * per_block, per_block * c->bc * 8) != 0)
+    return c->ctx->fail(LCP2_E_INVALID, "constants cap does not contain this shard's entries");
+  c->cs_cap.assign((const u64 *)cap, (const u64 *)cap + capw);
+  std::vector<u64> buf(c->cs_cap);
+  buf.push_back(c->p.degree_bits);
+  HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), c->digest);
+  c->cap_final = true;
   return LCP2_OK;
 }
 
@@ -321,7 +364,7 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, u64 *c
   }
   c->stage = 0;
   LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
-  LCP2_TRY(download(ctx, cap_out, c->wires.cap_dev(), L.capw * 8));
+  LCP2_TRY(download_cap(c, c->wires, cap_out));
   c->d_wires_cur = d_wires;
   c->stage = 1;
   return LCP2_OK;
@@ -354,15 +397,15 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
   }
   LCP2_HIP(ctx, hipGetLastError());
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
-  LCP2_TRY(download(ctx, cap_out, c->zs.cap_dev(), L.capw * 8));
+  LCP2_TRY(download_cap(c, c->zs, cap_out));
   c->stage = 2;
   return LCP2_OK;
 }
 
 // compute_quotient_polys + commitment (K6, K1-K4)
-int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs, u64 *cap_out) {
+int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage < 2) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
+  if (c->stage < 2 || c->stage == 25) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
   u64 *d_small = c->small.u();
   u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
   std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
@@ -382,11 +425,23 @@ int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs,
     a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.out = c->qvals.u();
     a.N = N; a.lgN = lgN; a.rate_bits = p.rate_bits; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors;
     a.num_constants = NC; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH; a.num_regs = c->num_regs;
+    a.leaf0 = (u64)c->bf * n; a.count = (u64)c->nblocks() * n; a.stride = a.count;
     if (be.status) return be.status;
-    ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)N * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH));
+    // a sharded circuit fills its own leaf blocks and leaves zeros elsewhere: the ranks' buffers sum (or OR) to the values
+    if (c->sharded()) LCP2_HIP(ctx, hipMemsetAsync(c->qvals.p, 0, (size_t)CH * N * 8, s));
+    ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)a.count * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH));
     launch_quotient(s, a);
   }
   LCP2_HIP(ctx, hipGetLastError());
+  LCP2_HIP(ctx, hipStreamSynchronize(s));
+  c->stage = 25;  // quotient values present (between stage 2 and 3)
+  return LCP2_OK;
+}
+
+// coset iNTT of the (complete) quotient values, chunking, commitment
+int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
+  LCP2_STAGE_PROLOGUE
+  if (c->stage != 25) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient_commit: no quotient values");
   LCP2_HIP(ctx, c->quot.coeffs.ensure((size_t)CH * N * 8));
   {
     ProfScope ps(ctx, LCP2_K_INTT, 16.0 * N * CH);
@@ -395,9 +450,15 @@ int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs,
   if (be.status) return be.status;
   // N = Q n: the 8n coefficients of challenge c are exactly its Q chunks of n coefficients, already contiguous
   LCP2_TRY(commit_coeffs_dev(ctx, c->quot.coeffs.u(), CH * Q, p.degree_bits, p.rate_bits, p.cap_height, &c->quot, false));
-  LCP2_TRY(download(ctx, cap_out, c->quot.cap_dev(), L.capw * 8));
+  LCP2_TRY(download_cap(c, c->quot, cap_out));
   c->stage = 3;
   return LCP2_OK;
+}
+
+int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs, u64 *cap_out) {
+  if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: use lcp2_quotient_values, exchange the buffer, then lcp2_quotient_commit");
+  LCP2_TRY(stage_quotient_values(c, alphas, public_inputs));
+  return stage_quotient_commit(c, cap_out);
 }
 
 // OpeningSet::new + PolynomialBatch::prove_openings (K7-K9, a13).  `ch` has observed everything up to the quotient cap and
@@ -405,7 +466,8 @@ int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs,
 // produced the query indices.  Writes proof words [op_constants, total).
 int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl2 &alpha, gl2 *fri_betas, u64 &pow_witness, std::vector<u64> &idx) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage < 3) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
+  if (c->stage != 3) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
+  if (!c->cap_final) return ctx->fail(LCP2_E_INVALID, "sharded circuit: lcp2_circuit_set_constants_cap has not been called");
   const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
   // ---- K7a: openings
   lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
@@ -544,16 +606,26 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     u64 xi = x;
     for (u32 l = 0; l < p.num_fri_layers; l++) { xi >>= p.fri_arity_bits[l]; idx[(1 + l) * Qn + q] = xi; }
   }
-  LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s));
+  // a sharded circuit answers the initial-tree part of the queries whose leaf it holds and leaves zeros for the others
+  // (its share of the proof); the FRI layers are replicated on every rank
+  const u64 leaf0 = (u64)c->bf * n, nlocal = (u64)c->nblocks() * n;
+  std::vector<u64> up(idx);
+  std::vector<char> mine(Qn, 1);
+  for (u32 q = 0; q < Qn; q++) {
+    mine[q] = idx[q] >= leaf0 && idx[q] < leaf0 + nlocal;
+    up.push_back(mine[q] ? idx[q] - leaf0 : 0);
+  }
+  LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, up.data(), up.size() * 8, hipMemcpyHostToDevice, s));
   {
     u64 *d_idx = c->q_idx.u();
+    const u64 *d_idx_local = d_idx + idx.size();
     u64 *buf = c->q_buf.u();
     size_t pos = 0;
     size_t o_leaf[4], o_sib[4], f_leaf[LCP2_MAX_FRI_LAYERS], f_sib[LCP2_MAX_FRI_LAYERS];
     for (int o = 0; o < 4; o++) {
       o_leaf[o] = pos; pos += (size_t)Qn * oracles[o]->ncols;
       o_sib[o] = pos; pos += (size_t)Qn * L.q_init_sib * 4;
-      LCP2_TRY(open_oracle(ctx, *oracles[o], d_idx, Qn, buf + o_leaf[o], buf + o_sib[o]));
+      LCP2_TRY(open_oracle(ctx, *oracles[o], d_idx_local, Qn, buf + o_leaf[o], buf + o_sib[o]));
     }
     for (u32 l = 0; l < p.num_fri_layers; l++) {
       const u32 arity = 1u << p.fri_arity_bits[l];
@@ -571,7 +643,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     LCP2_TRY(download(ctx, h.data(), buf, pos * 8));
     for (u32 q = 0; q < Qn; q++) {
       u64 *R = proof + L.queries + (size_t)q * L.query_words;
-      for (int o = 0; o < 4; o++) {
+      for (int o = 0; o < 4 && mine[q]; o++) {
         u32 nc = oracles[o]->ncols;
         memcpy(R + L.q_init_off[o], h.data() + o_leaf[o] + (size_t)q * nc, nc * 8);
         memcpy(R + L.q_init_off[o] + nc, h.data() + o_sib[o] + (size_t)q * L.q_init_sib * 4, L.q_init_sib * 32);
@@ -590,6 +662,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
 extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, uint64_t *proof_) {
   if (!c || !wires_in_ || !proof_ || (c->npi && !public_inputs_)) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;  // verifier-only circuit
+  if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: drive the stages and their exchange steps (parallel.py ShardedProver)");
   const u64 *public_inputs = (const u64 *)public_inputs_;
   u64 *proof = (u64 *)proof_;
   const lcp2_params &p = c->p;
@@ -648,6 +721,51 @@ extern "C" int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint
   if (!c->ctx) return LCP2_E_NODEVICE;
   return stage_quotient(c, (const u64 *)alphas, (const u64 *)public_inputs, (u64 *)cap);
 }
+extern "C" int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs) {
+  if (!c || !alphas || (c->npi && !public_inputs)) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_quotient_values(c, (const u64 *)alphas, (const u64 *)public_inputs);
+}
+extern "C" int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words) {
+  if (!c || !device_ptr || !words) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  *device_ptr = (uint64_t *)c->qvals.p;
+  *words = ((size_t)c->p.num_challenges << (c->p.degree_bits + c->p.rate_bits));
+  return LCP2_OK;
+}
+extern "C" int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap) {
+  if (!c || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_quotient_commit(c, (u64 *)cap);
+}
+// host-side transcript helpers (plonky2 Challenger / PoseidonHash::hash_no_pad) for callers without their own
+extern "C" void lcp2_challenger_init(lcp2_challenger *ch) { if (ch) memset(ch, 0, sizeof *ch); }
+extern "C" int lcp2_challenger_observe(lcp2_challenger *chs, const uint64_t *values, size_t count) {
+  if (!chs || (count && !values) || chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  HostChallenger ch;
+  ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
+  ch.observe_n((const u64 *)values, count);
+  ch.save((u64 *)chs->sponge, (u64 *)chs->input, chs->input_len, (u64 *)chs->output, chs->output_len);
+  return LCP2_OK;
+}
+extern "C" int lcp2_challenger_get(lcp2_challenger *chs, uint64_t *out, size_t count) {
+  if (!chs || (count && !out) || chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  HostChallenger ch;
+  ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
+  for (size_t i = 0; i < count; i++) out[i] = ch.get();
+  ch.save((u64 *)chs->sponge, (u64 *)chs->input, chs->input_len, (u64 *)chs->output, chs->output_len);
+  return LCP2_OK;
+}
+extern "C" int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]) {
+  if ((count && !values) || !out) return LCP2_E_INVALID;
+  std::vector<u64> v(std::max<size_t>(count, 1), 0);
+  for (size_t i = 0; i < count; i++) v[i] = gl_canon(values[i]);
+  u64 h[4];
+  HostPoseidon::get().hash_no_pad(v.data(), count, h);
+  memcpy(out, h, 32);
+  return LCP2_OK;
+}
+
 extern "C" int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *chs, uint64_t *proof) {
   if (!c || !zeta || !chs || !proof) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;

@@ -38,8 +38,11 @@ struct QuotientArgs {
   const u64 *k_is, *betas, *gammas, *alphas, *pis, *imm;
   const u32 *code;
   const GateDev *gates;
-  u64 *out;           // [CH][N] quotient values, leaf order
-  u64 N;
+  u64 *out;           // [CH][N] quotient values, leaf order (always the full domain)
+  u64 N;              // size of the LDE domain
+  // coset-sharded circuits hold only the leaf blocks [leaf0, leaf0 + count) of every LDE: `stride` is the column stride of
+  // wires / consts / zs (= count), l0 / points / out are indexed with the global leaf index.  Unsharded: 0, N, N.
+  u64 leaf0, count, stride;
   u32 lgN, rate_bits, num_gates, num_selectors, num_constants, num_routed, chunk, nchunks, num_challenges, num_regs;
 };
 

@@ -97,3 +97,93 @@ class GpuOps:
         buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(buf, t)
         return buf.cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One whole proof sharded by LDE coset (include/lcp2.h "one proof sharded over the GPUs of a node").
+class ShardedProver:
+    """Rank `rank` of `world` in a coset-sharded proof.  Every rank holds the whole witness and runs the same sequence of
+    seams on its own leaf blocks; results are shares that a bitwise-OR all-reduce assembles (caps, the proof array) plus one
+    bulk all-reduce of the quotient values.  `comm` supplies the two collectives:
+        comm.or_host(numpy uint64 array) -> numpy uint64 array       (tiny: 512-byte caps, the proof array)
+        comm.or_device(device pointer, uint64 words)                  (in place; 2 * 8n words: RCCL over xGMI)
+    so that the same orchestration runs over torch.distributed (TorchComm) and, in the single-GPU tests, over ranks that are
+    stepped in lockstep inside one process."""
+
+    def __init__(self, ctx, circ, rank, world, comm, constants_sigmas_ptr=None, mem=0):
+        from . import binding as b
+        self.b, self.circ, self.rank, self.world, self.comm = b, circ, rank, world, comm
+        first, count = block_range(rank, world, circ.params.rate_bits)
+        self.data = b.CircuitData.build_sharded(ctx, circ, first, count, constants_sigmas_ptr, mem)
+        self.cap_share = self.data.digest()[1]
+
+    def finish_build(self):
+        self.data.set_constants_cap(self.comm.or_host(self.cap_share))
+        self.digest = self.data.digest()[0]
+
+    # the proof as a generator of exchange points, so that a test can interleave several ranks in one process
+    def prove_steps(self, wires, public_inputs, mem=0):
+        b, d, p = self.b, self.data, self.circ.params
+        capw = 4 << p.cap_height
+        proof = np.zeros(d.proof_words, dtype=np.uint64)
+        pis = np.asarray(public_inputs, dtype=np.uint64)
+        ch = b.Challenger()
+        ch.observe(self.digest)
+        ch.observe(b.hash_no_pad(pis))
+        share = d.commit_wires(wires, mem)
+        proof[0:capw] = (yield ("or_host", share)).ravel()
+        ch.observe(proof[0:capw])
+        betas, gammas = ch.get(p.num_challenges), ch.get(p.num_challenges)
+        share = d.perm_zs(betas, gammas)
+        proof[capw:2 * capw] = (yield ("or_host", share)).ravel()
+        ch.observe(proof[capw:2 * capw])
+        alphas = ch.get(p.num_challenges)
+        d.quotient_values(alphas, pis)
+        yield ("or_device",) + d.quotient_buffer()
+        share = d.quotient_commit()
+        proof[2 * capw:3 * capw] = (yield ("or_host", share)).ravel()
+        ch.observe(proof[2 * capw:3 * capw])
+        zeta = ch.get(2)
+        caps = proof[:3 * capw].copy()
+        d.fri_open(zeta, ch.state, proof)
+        proof[:3 * capw] = caps
+        proof = (yield ("or_host", proof))
+        self.proof = proof
+        return
+
+    def prove(self, wires, public_inputs, mem=0):
+        steps = self.prove_steps(wires, public_inputs, mem)
+        reply = None
+        try:
+            while True:
+                req = steps.send(reply)
+                if req[0] == "or_host":
+                    reply = self.comm.or_host(req[1])
+                else:
+                    self.comm.or_device(req[1], req[2])
+                    reply = None
+        except StopIteration:
+            return self.proof
+
+
+class TorchComm:
+    """torch.distributed collectives for ShardedProver: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" on CPU."""
+
+    def __init__(self, dist, device=None, ctx=None):
+        self.dist, self.device, self.ctx = dist, device, ctx
+
+    def or_host(self, arr):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.BOR)
+        return t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
+
+    def or_device(self, ptr, words):
+        import torch
+        t = torch.empty(words, dtype=torch.int64, device=self.device)  # staging tensor: two device copies (< 1 ms at 537 MB)
+        self.ctx.buffer_copy(t.data_ptr(), ptr, words)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.BOR)
+        torch.cuda.synchronize()
+        self.ctx.buffer_copy(ptr, t.data_ptr(), words)

@@ -149,6 +149,8 @@ int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev);
 int lcp2_buffer_free(lcp2_ctx *ctx, void *dev);
 int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes);
 int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int lcp2_buffer_write(lcp2_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_src, size_t bytes);   /* device to device, on the context's stream */
 
 /* ------------------------------------------------------------------ polynomial commitments
  * PolynomialBatch::from_values / from_coeffs (plonky2 fri/oracle.rs): ifft,
@@ -262,6 +264,32 @@ typedef struct {
  * drawn.  proof: a buffer of lcp2_proof_words(); words from the openings to the end are written (the three caps in
  * front of them are the caller's). */
 int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *ch, uint64_t *proof);
+
+/* host-side transcript helpers for callers that do not bring their own Challenger / PoseidonHash (no device work) */
+void lcp2_challenger_init(lcp2_challenger *ch);
+int lcp2_challenger_observe(lcp2_challenger *ch, const uint64_t *values, size_t count);
+int lcp2_challenger_get(lcp2_challenger *ch, uint64_t *out, size_t count);   /* challenges pop from the back of the output buffer */
+int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* PoseidonHash::hash_no_pad (public-input hash) */
+
+/* ---- one proof sharded over the GPUs of a node by LDE coset (BASELINE configs[3]).
+ * A sharded circuit holds the leaf blocks [block_first, block_first + block_count) of every LDE and Merkle tree
+ * (block_count a power of two dividing 2^rate_bits, block_first aligned to it, cap_height >= rate_bits so that a block is
+ * whole cap subtrees: no cross-GPU hashing).  Every rank gets the whole witness and runs the same call sequence as the
+ * seams above; what a rank returns is its SHARE of the result - its own cap entries / query answers at their global
+ * position, zeros elsewhere, replicated parts identical on every rank - so one bitwise-OR all-reduce of each cap and of
+ * the proof array assembles the result.  The only bulk exchange is the quotient values (num_challenges * 8n words): each
+ * rank fills its blocks of lcp2_quotient_buffer (zeros elsewhere), the caller sum-/OR-all-reduces that buffer in place
+ * over RCCL, then every rank calls lcp2_quotient_commit.  Order per proof:
+ *   lcp2_commit_wires -> OR caps -> lcp2_perm_zs -> OR caps -> lcp2_quotient_values -> all-reduce buffer ->
+ *   lcp2_quotient_commit -> OR caps -> lcp2_fri_open -> OR proofs.
+ * At build: lcp2_circuit_create_sharded, lcp2_circuit_digest (cap share; digest not valid yet), OR the cap,
+ * lcp2_circuit_set_constants_cap.  lcp2_prove / lcp2_quotient refuse a sharded circuit. */
+int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, uint32_t block_first, uint32_t block_count,
+                                lcp2_circuit **out);
+int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap);
+int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs);
+int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words);
+int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap);
 
 /* data.verify(proof): host only (no device work).  LCP2_OK or LCP2_E_VERIFY; *failed_check (nullable):
  * 1 encoding, 2 proof of work, 3 vanishing identity, 4 initial Merkle proof, 5 FRI consistency,

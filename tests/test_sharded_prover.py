@@ -1,0 +1,165 @@
+"""One proof sharded by LDE coset over 2 / 4 / 8 ranks (BASELINE configs[3]; include/lcp2.h "one proof sharded
+over the GPUs of a node").  On the single test GPU the ranks are separate sharded circuit handles stepped in lockstep in
+one process, the collectives are emulated on the host; the assembled proof must equal the single-GPU proof word for word
+(which itself equals the oracle's, test_gpu_prover.py).  The torch.distributed collectives are covered on CPU with gloo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class LockstepComm:
+    """collectives of `world` ranks that live in one process: requests are collected from every rank, then answered"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def or_host_all(self, arrays):
+        acc = np.zeros_like(arrays[0])
+        for a in arrays:
+            acc |= a
+        return acc
+
+    def or_device_all(self, bufs):
+        acc = None
+        for ptr, words in bufs:
+            v = self.ctx.buffer_read(ptr, words)
+            acc = v if acc is None else acc | v
+        for ptr, words in bufs:
+            self.ctx.buffer_write(ptr, acc)
+
+
+def _run_lockstep(m, ctx, circ, wires, pis, world):
+    comm = LockstepComm(ctx)
+    ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
+    cap = comm.or_host_all([r.cap_share for r in ranks])
+    for r in ranks:
+        r.comm = type("C", (), {"or_host": staticmethod(lambda a, cap=cap: cap)})()
+        r.finish_build()
+    gens = [r.prove_steps(wires, pis) for r in ranks]
+    replies = [None] * world
+    while True:
+        reqs = []
+        for g, rep in zip(gens, replies):
+            try:
+                reqs.append(g.send(rep))
+            except StopIteration:
+                reqs.append(None)
+        if all(q is None for q in reqs):
+            break
+        assert all(q is not None and q[0] == reqs[0][0] for q in reqs), "ranks diverged"
+        if reqs[0][0] == "or_host":
+            merged = comm.or_host_all([q[1] for q in reqs])
+            replies = [merged.copy() for _ in range(world)]
+        else:
+            comm.or_device_all([(q[1], q[2]) for q in reqs])
+            replies = [None] * world
+    return ranks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,degree_bits", [(2, 9), (4, 8), (8, 10), (8, 5)])
+def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits):
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(degree_bits, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=900 + world)
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, world)
+    for r in ranks:
+        assert (r.digest == single.digest()[0]).all()
+        bad = np.nonzero(r.proof != want)[0]
+        assert bad.size == 0, f"rank {r.rank}/{world}: {bad.size} proof words differ, first at {bad[0]}"
+    single.verify(ranks[0].proof, pis)
+    # the shares really are shares: a rank answers only the queries whose leaves it holds
+    with pytest.raises(m.Lcp2Error):
+        ranks[0].data.prove(wires, pis)  # a sharded handle refuses the monolithic call
+    for r in ranks:
+        r.data.close()
+    single.close()
+
+
+def test_host_transcript_helpers_match_oracle(oracle):
+    """lcp2_challenger_* / lcp2_hash_no_pad (host C++) against the oracle's Poseidon"""
+    import eth_lc_plonky2_amd as m
+    import oracle_lib
+    rng = np.random.default_rng(5)
+    P = m.GOLDILOCKS_P
+    vals = rng.integers(0, P, size=41, dtype=np.uint64)
+    want = np.zeros(4, dtype=np.uint64)
+    oracle.orc_hash_no_pad(oracle_lib.vp(vals), len(vals), oracle_lib.vp(want))
+    assert (m.binding.hash_no_pad(vals) == want).all()
+    # duplex challenger: observe 13, draw 3, observe 2, draw 9 (crosses a squeeze boundary)
+    ch = m.binding.Challenger()
+    s, inp, out, got = np.zeros(12, dtype=np.uint64), [], [], []
+
+    def duplex():
+        nonlocal inp, out
+        for i, v in enumerate(inp):
+            s[i] = v
+        inp = []
+        oracle.orc_poseidon_permute(oracle_lib.vp(s))
+        out = [int(v) for v in s[:8]]
+
+    def observe(xs):
+        nonlocal inp, out
+        for x in xs:
+            out = []
+            inp.append(int(x))
+            if len(inp) == 8:
+                duplex()
+
+    def get(k):
+        r = []
+        for _ in range(k):
+            if inp or not out:
+                duplex()
+            r.append(out.pop())
+        return r
+
+    ch.observe(vals[:13]); observe(vals[:13])
+    assert list(ch.get(3)) == get(3)
+    ch.observe(vals[13:15]); observe(vals[13:15])
+    assert list(ch.get(9)) == get(9)
+
+
+_GLOO_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import eth_lc_plonky2_amd as m
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+comm = m.parallel.TorchComm(dist)
+# cap shares: rank r owns entries [8r, 8r + 8) of a 16-entry cap
+share = np.zeros((16, 4), dtype=np.uint64)
+share[8 * rank:8 * rank + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) + np.uint64(1000 * (rank + 1)) + (np.uint64(1) << np.uint64(63))
+full = comm.or_host(share)
+want = np.zeros((16, 4), dtype=np.uint64)
+for r in range(2):
+    want[8 * r:8 * r + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) + np.uint64(1000 * (r + 1)) + (np.uint64(1) << np.uint64(63))
+assert (full == want).all() and full.dtype == np.uint64
+# replicated words stay what they are
+rep = np.array([5, 2**64 - 1, 0, 77], dtype=np.uint64)
+assert (comm.or_host(rep) == rep).all()
+assert m.parallel.block_range(rank, 2) == (4 * rank, 4)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_torch_comm_or_allreduce_gloo(tmp_path):
+    """world_size-2 gloo: the OR all-reduce that assembles caps and the proof from the ranks' shares (full 64-bit words)"""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""One light-client-sized proof sharded by LDE coset over the GPUs of one node (BASELINE configs[3]).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_proof_demo.py [--degree-bits 22]
+
+Every rank builds the same synthetic circuit and witness (same seed), holds 8/N leaf blocks of every LDE / Merkle tree and
+proves through eth-lc-plonky2_amd/parallel.py::ShardedProver: four 512-byte OR all-reduces, one OR all-reduce of the proof
+array and one bulk all-reduce of the quotient values (2 * 8n words) over RCCL.  Rank 0 verifies the assembled proof and
+prints the wall time per proof.  With N = 1 the same code path runs with one rank holding all 8 blocks (the only case a
+one-GPU box can run; the multi-rank data flow is covered by tests/test_sharded_prover.py with the ranks in lockstep on
+one GPU)."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class _Solo:  # N = 1: the collectives are the identity
+    def or_host(self, a):
+        return a
+
+    def or_device(self, ptr, words):
+        pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--degree-bits", type=int, default=22)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--rehearse", default="", help="R/W: time the compute of rank R of W on this one GPU (collectives replaced by "
+                    "the identity, so the transcript is not the real one and the proof is not verified)")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    import eth_lc_plonky2_amd as m
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ctx = m.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    params = m.standard_params(a.degree_bits, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=4242)
+    comm = m.parallel.TorchComm(dist, torch.device("cuda", local), ctx) if world > 1 else _Solo()
+    rehearse = None
+    if a.rehearse:
+        rehearse = tuple(int(x) for x in a.rehearse.split("/"))
+        rank, world = rehearse
+    t0 = time.time()
+    prover = m.parallel.ShardedProver(ctx, circ, rank, world, comm)
+    prover.finish_build()
+    build_s = time.time() - t0
+    d_wires = torch.from_numpy(wires.view("int64")).cuda()  # witness resident in HBM, as in bench.py
+    times = []
+    for _ in range(a.reps):
+        if world > 1 and not rehearse:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        proof = prover.prove(d_wires.data_ptr(), pis, mem=m.MEM_DEVICE)
+        torch.cuda.synchronize()
+        times.append(time.time() - t0)
+    if rehearse:
+        print("rehearsal of rank %d of %d, degree_bits %d: build %.2f s, per-rank compute of a sharded proof %s ms (exchanges excluded)"
+              % (rank, world, a.degree_bits, build_s, ", ".join("%.1f" % (1e3 * t) for t in times)))
+        return
+    if rank == 0:
+        digest, _ = prover.data.digest()
+        vd = m.CircuitData.verifier_only(circ, digest, prover.data.digest()[1])
+        vd.verify(proof, pis)
+        print("world %d degree_bits %d: build %.2f s, sharded proof %s ms (verified)" % (world, a.degree_bits, build_s,
+              ", ".join("%.1f" % (1e3 * t) for t in times)))
+    if world > 1 and not rehearse:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
