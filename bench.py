@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one wave64 instruction per 4 cycles per SIMD
+POSEIDON_VALU_INSTR = 8 * 1209 + 22 * 484 + 118  # census of the compiled permutation
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench
 
@@ -148,6 +150,9 @@ def main():
         lh = prof_all["leaf_hash"]  # every k_hash_leaves launch of this process, as rocprofv3 --stats averages them
         avg_ms = lh["ms"] / max(lh["launches"], 1)
         achieved = (lh["bytes"] / max(lh["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the kernel is integer-VALU bound: permutations/s x instructions per permutation against the VALU issue peak
+        perms = (-(-params.num_wires // 8) + 3 + 2) * float(1 << (a.degree_bits + 3)) * a.steps  # wires, 20 Z columns, 16 quotient chunks
+        perms_per_s = perms / max(prof["leaf_hash"]["ms"] * 1e-3, 1e-12)
         kern = {}
         for k, v in prof.items():
             if v["launches"]:
@@ -166,7 +171,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves", lh["bytes"] / max(lh["launches"], 1)),
                          "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
-                         "note": "integer-ALU bound (Poseidon): see DESIGN.md; HBM fraction is legitimately low"},
+                         "note": "integer-VALU bound (Poseidon), so the HBM fraction is legitimately low: see `valu` and DESIGN.md section 3",
+                         "valu": {"permutations_per_s": perms_per_s, "valu_instructions_per_permutation": POSEIDON_VALU_INSTR,
+                                  "achieved_lane_instr_per_s": perms_per_s * POSEIDON_VALU_INSTR, "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
+                                  "frac": perms_per_s * POSEIDON_VALU_INSTR / VALU_PEAK_LANE_INSTR}},
             "kernels": kern,
         }
         if not a.no_cpu_baseline and world == 1:

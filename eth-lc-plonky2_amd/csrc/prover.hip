@@ -35,7 +35,8 @@ struct lcp2_circuit {
   DevBuf q_idx, q_buf;
   // staged proving (lcp2_commit_wires -> lcp2_perm_zs -> lcp2_quotient -> lcp2_fri_open)
   const u64 *d_wires_cur = nullptr;
-  int stage = 0;
+  enum Stage { ST_NONE = 0, ST_WIRES, ST_ZS, ST_QVALS, ST_QUOT };  // what the handle holds of the proof in flight
+  Stage stage = ST_NONE;
   // coset-sharded circuit: this handle holds the leaf blocks [bf, bf + bc) of every LDE and Merkle tree;
   // bc = 0: all of them.  cap_final: the full constants_sigmas cap (hence the digest) is known.
   uint32_t bf = 0, bc = 0;
@@ -362,18 +363,18 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, u64 *c
     LCP2_HIP(ctx, hipMemcpyAsync(c->wires_vals.p, wires_in, (size_t)W * n * 8, hipMemcpyHostToDevice, s));
     d_wires = c->wires_vals.u();
   }
-  c->stage = 0;
+  c->stage = lcp2_circuit::ST_NONE;
   LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
   LCP2_TRY(download_cap(c, c->wires, cap_out));
   c->d_wires_cur = d_wires;
-  c->stage = 1;
+  c->stage = lcp2_circuit::ST_WIRES;
   return LCP2_OK;
 }
 
 // wires_permutation_partial_products_and_zs + commitment (K5, K1-K4)
 int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap_out) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage < 1) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
+  if (c->stage < lcp2_circuit::ST_WIRES) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
   const u64 *d_wires = c->d_wires_cur;
   u64 *d_small = c->small.u();
   u64 *d_betas = d_small, *d_gammas = d_small + 4;
@@ -398,14 +399,14 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
   LCP2_HIP(ctx, hipGetLastError());
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
   LCP2_TRY(download_cap(c, c->zs, cap_out));
-  c->stage = 2;
+  c->stage = lcp2_circuit::ST_ZS;
   return LCP2_OK;
 }
 
 // compute_quotient_polys + commitment (K6, K1-K4)
 int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage < 2 || c->stage == 25) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
+  if (c->stage < lcp2_circuit::ST_ZS) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
   u64 *d_small = c->small.u();
   u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
   std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
@@ -434,14 +435,14 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *public_
   }
   LCP2_HIP(ctx, hipGetLastError());
   LCP2_HIP(ctx, hipStreamSynchronize(s));
-  c->stage = 25;  // quotient values present (between stage 2 and 3)
+  c->stage = lcp2_circuit::ST_QVALS;
   return LCP2_OK;
 }
 
 // coset iNTT of the (complete) quotient values, chunking, commitment
 int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage != 25) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient_commit: no quotient values");
+  if (c->stage != lcp2_circuit::ST_QVALS) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient_commit: no quotient values");
   LCP2_HIP(ctx, c->quot.coeffs.ensure((size_t)CH * N * 8));
   {
     ProfScope ps(ctx, LCP2_K_INTT, 16.0 * N * CH);
@@ -451,7 +452,7 @@ int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
   // N = Q n: the 8n coefficients of challenge c are exactly its Q chunks of n coefficients, already contiguous
   LCP2_TRY(commit_coeffs_dev(ctx, c->quot.coeffs.u(), CH * Q, p.degree_bits, p.rate_bits, p.cap_height, &c->quot, false));
   LCP2_TRY(download_cap(c, c->quot, cap_out));
-  c->stage = 3;
+  c->stage = lcp2_circuit::ST_QUOT;
   return LCP2_OK;
 }
 
@@ -466,7 +467,7 @@ int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs,
 // produced the query indices.  Writes proof words [op_constants, total).
 int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl2 &alpha, gl2 *fri_betas, u64 &pow_witness, std::vector<u64> &idx) {
   LCP2_STAGE_PROLOGUE
-  if (c->stage != 3) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
+  if (c->stage != lcp2_circuit::ST_QUOT) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
   if (!c->cap_final) return ctx->fail(LCP2_E_INVALID, "sharded circuit: lcp2_circuit_set_constants_cap has not been called");
   const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
   // ---- K7a: openings
