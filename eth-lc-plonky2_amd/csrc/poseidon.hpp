@@ -94,33 +94,40 @@ LCP2_HD void pos_permute_portable(u64 s[12], const u64 *__restrict__ rc) {
 // carry-in reader: 1, -> e64 reader of vcc: 2) are written out as s_nop here.
 // All values are lazy (any u64 congruent to the element); the final state is canonicalised.
 
-__device__ __forceinline__ void pos_mul_h(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) { gl_mul_halves(a0, a1, b0, b1, r0, r1); }
+// the select constants of gl_mul_halves_k / pos_fold_h, made opaque to the compiler so that they are materialised once per
+// permutation and not rematerialised (a v_mov per use would cost what the VOP2 select saves)
+struct PosK { u32 one, ones; };
+__device__ __forceinline__ PosK pos_consts() {
+  PosK k;
+  asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %1, -1" : "=v"(k.one), "=v"(k.ones));
+  return k;
+}
 
-__device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1) {
+__device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1, const PosK k) {
   u32 a0, a1, b0, b1, c0, c1;
-  pos_mul_h(x0, x1, x0, x1, a0, a1);  // x^2
-  pos_mul_h(a0, a1, a0, a1, b0, b1);  // x^4
-  pos_mul_h(x0, x1, a0, a1, c0, c1);  // x^3
-  pos_mul_h(c0, c1, b0, b1, x0, x1);  // x^7
+  gl_mul_halves_k(x0, x1, x0, x1, a0, a1, k.one, k.ones);  // x^2
+  gl_mul_halves_k(a0, a1, a0, a1, b0, b1, k.one, k.ones);  // x^4
+  gl_mul_halves_k(x0, x1, a0, a1, c0, c1, k.one, k.ones);  // x^3
+  gl_mul_halves_k(c0, c1, b0, b1, x0, x1, k.one, k.ones);  // x^7
 }
 
 // al + ah * 2^32 (al, ah < 2^42) -> lazy 64-bit value:  t = al + ah_hi * (2^64 mod p) ;  v = t + (ah_lo << 32), on carry += 2^32 - 1
-__device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1) {
+__device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1, const PosK k) {
   const u64 t = (u64)(u32)(ah >> 32) * 0xFFFFFFFFu + al;
   const u32 t0 = (u32)t, t1 = (u32)(t >> 32), ah0 = (u32)ah;
   u32 e;
   asm("v_add_co_u32 %1, vcc, %4, %5\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+      "s_nop 0\n\t"
+      "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
       "v_add_co_u32 %0, vcc, %3, %2\n\t"
       "s_nop 0\n\t"
       "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(r0), "=&v"(r1), "=&v"(e) : "v"(t0), "v"(t1), "v"(ah0) : "vcc");
+      : "=&v"(r0), "=&v"(r1), "=&v"(e) : "v"(t0), "v"(t1), "v"(ah0), "v"(k.ones) : "vcc");
 }
 
 // state <- MDS(state) + add[0..12) ; add = the next round's constants (or nullptr): the constants ride in the
 // initial value of the accumulators, so the add-round-constant layer costs nothing.
-__device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add) {
+__device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add, const PosK k) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u32 nl[12], nh[12];
 #pragma unroll
@@ -133,13 +140,14 @@ __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__r
       ah += (u64)hi[(i + r) % 12] * C[i];
     }
     if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-    pos_fold_h(al, ah, nl[r], nh[r]);
+    pos_fold_h(al, ah, nl[r], nh[r], k);
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
 }
 
 __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restrict__ rc) {
+  const PosK k = pos_consts();
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) { u64 v = gl_add_nc(s[i], rc[i]); lo[i] = (u32)v; hi[i] = (u32)(v >> 32); }
@@ -147,23 +155,23 @@ __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restr
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_PARTIAL; r++, round++) {
-    pos_sbox_h(lo[0], hi[0]);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+    pos_sbox_h(lo[0], hi[0], k);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF - 1; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12);
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
   }
 #pragma unroll
-  for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
-  pos_mds_h(lo, hi, nullptr);
+  for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
+  pos_mds_h(lo, hi, nullptr, k);
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(((u64)hi[i] << 32) | lo[i]);
 }
@@ -176,6 +184,7 @@ __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restr
 // POS_COOP_MAX_NODES nodes.  v: element j of the state (any u64); returns the canonical output element j.
 __device__ __forceinline__ u64 pos_permute_coop(u64 v, u32 j, const u64 *__restrict__ rc /* LDS copy of the round constants */) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  const PosK k = pos_consts();
   const u32 lane = __lane_id(), jj = j < 12 ? j : 0, base = lane - j;
   u32 src[12];
 #pragma unroll
@@ -193,27 +202,27 @@ __device__ __forceinline__ u64 pos_permute_coop(u64 v, u32 j, const u64 *__restr
       ah += (u64)vh * C[i];
     }
     if (j == 0) { al += (u64)lo * 8u; ah += (u64)hi * 8u; }
-    pos_fold_h(al, ah, lo, hi);
+    pos_fold_h(al, ah, lo, hi, k);
   };
   int round = 0;
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
     const u64 next = rc[(round + 1) * 12 + jj];
-    pos_sbox_h(lo, hi);
+    pos_sbox_h(lo, hi, k);
     mds(next);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_PARTIAL; r++, round++) {
     const u64 next = rc[(round + 1) * 12 + jj];
     u32 s0 = lo, s1 = hi;
-    pos_sbox_h(s0, s1);
+    pos_sbox_h(s0, s1, k);
     if (j == 0) { lo = s0; hi = s1; }
     mds(next);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
     const u64 next = round + 1 < POS_ROUNDS ? rc[(round + 1) * 12 + jj] : 0;
-    pos_sbox_h(lo, hi);
+    pos_sbox_h(lo, hi, k);
     mds(next);
   }
   return gl_canon(((u64)hi << 32) | lo);
