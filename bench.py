@@ -46,6 +46,34 @@ def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
         return None
 
 
+def real_lc_step():
+    """Not the headline number: the reference's own update pair 633 -> 634 through examples/lc_prover (the C++ host layer's
+    light-client circuit in its own SHA-256 layout, 2^19 rows, BLS verifier stubbed), if the binary has been built."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "examples", "lc_prover")
+    golden = os.path.join(ROOT, "tests", "golden", "lc_updates.json")
+    if not (os.path.exists(exe) and os.path.exists(golden)):
+        return None
+    try:
+        lc = json.load(open(golden))
+        with tempfile.TemporaryDirectory() as d:
+            paths = []
+            for tag in ("633", "634"):
+                paths.append(os.path.join(d, "u%s.json" % tag))
+                json.dump(lc[tag], open(paths[-1], "w"))
+            r = subprocess.run([exe] + paths + ["--repeat", "3"], capture_output=True, text=True, timeout=120)
+        ms = [float(x) for x in re.findall(r"proved in ([0-9.]+) ms", r.stdout)]
+        bits = re.search(r"degree_bits (\d+)", r.stdout)
+        if r.returncode != 0 or len(ms) < 3 or not bits:
+            return None
+        return {"workload": "light-client step for updates 633 -> 634 (examples/lc_prover), device witness generation included, proof verified",
+                "degree_bits": int(bits.group(1)), "ms_per_proof": min(ms[1:])}
+    except Exception:  # a side measurement must never take the bench line down
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +207,9 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample_bits, a.degree_bits), a.degree_bits)
+            step_633 = real_lc_step()
+            if step_633:
+                out["config"]["real_lc_step"] = step_633
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

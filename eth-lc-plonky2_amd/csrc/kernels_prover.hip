@@ -198,8 +198,13 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
     u64 acc[QUOTIENT_MAX_CH];
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) acc[c] = 0;
+    // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
+    // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
+    const uint2 *code2 = (const uint2 *)a.code;
+    uint2 nxt = code2[G.code_offset];
     for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
-      const u32 w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
+      const u32 w0 = nxt.x, w1 = nxt.y;
+      nxt = code2[pc + 1];
       const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
       u64 x = q_operand(a, ka, ia, lds, T, tid, i);
       if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {

@@ -152,7 +152,11 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits;
   const u32 ncs = p.num_constants + p.num_routed_wires, CH = p.num_challenges, npp = npp_of(p), nchunks = npp + 1;
   LCP2_TRY(upload(ctx, c->d_gates, c->gates.data(), c->gates.size() * sizeof(lcp2_gate)));
-  LCP2_TRY(upload(ctx, c->d_code, c->code.data(), c->code.size() * 4));
+  {  // padded by two instructions: K6 fetches one instruction ahead of the one it executes
+    std::vector<uint32_t> padded(c->code);
+    padded.resize(padded.size() + 4, 0);
+    LCP2_TRY(upload(ctx, c->d_code, padded.data(), padded.size() * 4));
+  }
   LCP2_TRY(upload(ctx, c->d_imm, c->imm.data(), c->imm.size() * 8));
   LCP2_TRY(upload(ctx, c->d_kis, c->k_is.data(), c->k_is.size() * 8));
   // constants_sigmas values stay resident (K5 reads the sigma columns on H)
