@@ -108,6 +108,23 @@ Target CircuitBuilder::add_many(const std::vector<Target> &terms) {
 BoolTarget CircuitBuilder::not_(BoolTarget b) { return BoolTarget{arithmetic(impl_.get(), GOLDILOCKS_P - 1, b.target, one(), 1, one())}; }
 Target CircuitBuilder::select(BoolTarget b, Target x, Target y) { return mul_add(b.target, sub(x, y), y); }
 void CircuitBuilder::assert_bool(BoolTarget b) { connect(mul(b.target, b.target), b.target); }
+Target CircuitBuilder::le_sum(const std::vector<BoolTarget> &bits, size_t first, size_t count) {
+  if (first >= bits.size()) return zero();
+  const size_t end = count == (size_t)-1 || first + count > bits.size() ? bits.size() : first + count;
+  Target acc = bits[end - 1].target;
+  for (size_t i = end - 1; i-- > first;) acc = arithmetic(impl_.get(), 2, acc, one(), 1, bits[i].target);  // 2 acc + bit
+  return acc;
+}
+std::vector<BoolTarget> CircuitBuilder::split_le(Target x, size_t nbits) {
+  if (nbits == 0 || nbits > 63) throw std::runtime_error("split_le: 1..63 bits");
+  Op op; op.kind = Op::BITS; op.x = x.id; op.c0 = nbits;
+  std::vector<BoolTarget> bits;
+  for (size_t i = 0; i < nbits; i++) { BoolTarget b{add_virtual_target()}; op.internal.push_back(b.target.id); bits.push_back(b); }
+  impl_->d->ops.push_back(op);
+  for (auto &b : bits) assert_bool(b);
+  connect(le_sum(bits), x);
+  return bits;
+}
 
 void CircuitBuilder::connect(Target a, Target b) {
   auto &p = impl_->d->parent;
@@ -358,6 +375,14 @@ void eval_sha(const Op &op, Values &V, std::vector<uint64_t> &wires, uint64_t n)
 }
 }  // namespace
 
+// split_le generator: the low c0 bits of x; a value that does not fit cannot satisfy the recomposition constraint
+static void eval_bits(const Op &op, Values &V) {
+  const F x = V.get(op.x, "split_le input");
+  const unsigned nbits = (unsigned)op.c0;
+  if (nbits < 64 && (x >> nbits) != 0) throw UnsatisfiedError("split_le: value does not fit in " + std::to_string(nbits) + " bits (range check fails)");
+  for (unsigned i = 0; i < nbits; i++) V.set(op.internal[i], (x >> i) & 1, "split_le bit");
+}
+
 void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_t> &wires, std::vector<F> &public_inputs) const {
   const Impl *d = impl_.get();
   const uint64_t n = 1ull << desc_.params.degree_bits;
@@ -369,6 +394,7 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
   auto ready = [&](const Op &op) {
     auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
     if (op.kind == Op::ARITH) return has(op.x) && has(op.y) && has(op.z);
+    if (op.kind == Op::BITS) return has(op.x);
     if (op.kind == Op::SHA) { for (uint32_t v : op.in) if (!has(v)) return false; }
     return true;
   };
@@ -387,6 +413,7 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
           break;
         }
         case Op::SHA: eval_sha(op, V, wires, n); break;
+        case Op::BITS: eval_bits(op, V); break;
       }
     }
     if (waiting.size() == pending.size()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
@@ -436,7 +463,9 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       std::vector<const Op *> waiting;
       for (const Op *op : host_ops) {
         if (op->kind == Op::ARITH && !(has(op->x) && has(op->y) && has(op->z))) { waiting.push_back(op); continue; }
+        if (op->kind == Op::BITS && !has(op->x)) { waiting.push_back(op); continue; }
         if (op->kind == Op::CONST) V.set(op->out, op->c0, "constant");
+        else if (op->kind == Op::BITS) eval_bits(*op, V);
         else V.set(op->out, f_add(f_mul(f_mul(V.get(op->x, "x"), V.get(op->y, "y")), op->c0), f_mul(V.get(op->z, "z"), op->c1)), "arithmetic output");
         progress = true;
       }

@@ -230,14 +230,45 @@ VerifySyncCommitteeTarget add_virtual_verify_sync_committe_target(CircuitBuilder
   return t;
 }
 
-// src/targets.rs:184-235 with the BigUint period arithmetic stubbed (see gadgets.hpp)
+// src/utils.rs:93-113 for a u64 (see gadgets.hpp)
+SlotConnectTarget add_virtual_biguint_hash256_connect_target(CircuitBuilder &builder) {
+  SlotConnectTarget t;
+  t.h256 = builder.add_virtual_hash256_target();
+  for (int limb = 0; limb < 2; limb++) {
+    // bit k of the big-endian u32 limb; integer bit 8a + j of this limb's 4 bytes is limb bit 24 - 8a + j
+    std::vector<BoolTarget> be = builder.split_le(t.h256[limb].t, 32);
+    for (int a = 0; a < 4; a++)
+      for (int j = 0; j < 8; j++) t.bits.push_back(be[24 - 8 * a + j]);
+  }
+  for (int limb = 2; limb < 8; limb++) builder.connect(t.h256[limb].t, builder.zero());
+  builder.connect(t.bits[63].target, builder.zero());
+  t.value = builder.le_sum(t.bits, 0, 63);
+  return t;
+}
+
 FindSyncCommitteeTarget add_virtual_find_sync_committee_target(CircuitBuilder &builder) {
   FindSyncCommitteeTarget t;
-  t.is_attested_from_next_period = builder.add_virtual_bool_target_safe();
+  t.attested_slot = add_virtual_biguint_hash256_connect_target(builder);
+  t.cur_slot = add_virtual_biguint_hash256_connect_target(builder);
   t.cur_sync_committee_i = builder.add_virtual_hash256_target();
   t.cur_sync_committee_ii = builder.add_virtual_hash256_target();
+  // N_SLOTS_PER_PERIOD = 2^13: the period is the slot without its 13 low bits
+  Target attested_period = builder.le_sum(t.attested_slot.bits, 13, 50), cur_period = builder.le_sum(t.cur_slot.bits, 13, 50);
+  t.is_attested_from_next_period = BoolTarget{builder.sub(attested_period, cur_period)};
+  builder.assert_bool(t.is_attested_from_next_period);  // attested period is the current one (0) or the next (1)
   for (int i = 0; i < 8; i++)
     t.sync_committee_for_attested_slot[i] = U32Target{builder.select(t.is_attested_from_next_period, t.cur_sync_committee_ii[i].t, t.cur_sync_committee_i[i].t)};
+  return t;
+}
+
+UpdateValidityTarget add_virtual_update_validity_target(CircuitBuilder &builder) {
+  UpdateValidityTarget t;
+  t.cur_slot = builder.add_virtual_target();
+  t.finalized_slot = builder.add_virtual_target();
+  t.participation = builder.add_virtual_target();
+  builder.split_le(builder.sub(t.finalized_slot, t.cur_slot), 63);  // cur_slot <= finalized_slot (both < 2^63)
+  Target over = builder.sub(t.participation, builder.constant((F)(FINALITY_THRESHOLD + 1)));
+  builder.split_le(over, 10);                                       // participation > FINALITY_THRESHOLD (at most 512)
   return t;
 }
 
@@ -283,6 +314,8 @@ ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
   ContractStateTarget contract_state_target = add_virtual_contract_state_target(builder);
   FindSyncCommitteeTarget find_sync_committee_target = add_virtual_find_sync_committee_target(builder);
   VerifySyncCommitteeTarget verify_sync_committe_target = add_virtual_verify_sync_committe_target(builder);
+  UpdateValidityTarget update_validity_target = add_virtual_update_validity_target(builder);
+  SlotConnectTarget finalized_slot_connect = add_virtual_biguint_hash256_connect_target(builder);
 
   // *** signing root ***   (the recursive BLS verifier that consumes signing_root_bytes / signature_bytes is stubbed)
   builder.connect_hash256(signing_root_target.signing_root, signing_root);
@@ -306,7 +339,9 @@ ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
   builder.connect_hash256(finalized.proposer_index, p.finalized_proposer_index);
   builder.connect_hash256(finalized.slot, p.finalized_slot);
   builder.connect_hash256(finalized.state_root, p.finalized_state_root);
-  // *** sync committee ***
+  // *** sync committee ***   (targets.rs:541-542, 627-635: the slots enter through their Hash256 encodings)
+  builder.connect_hash256(find_sync_committee_target.cur_slot.h256, p.cur_slot);
+  builder.connect_hash256(find_sync_committee_target.attested_slot.h256, p.attested_slot);
   builder.connect_hash256(find_sync_committee_target.cur_sync_committee_i, p.cur_sync_committee_i);
   builder.connect_hash256(find_sync_committee_target.cur_sync_committee_ii, p.cur_sync_committee_ii);
   builder.connect_hash256(find_sync_committee_target.sync_committee_for_attested_slot, sync_committee_ssz);
@@ -319,6 +354,11 @@ ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
   builder.connect_hash256(verify_sync_committe_target.finalized_state_root, p.attested_state_root);
   for (size_t i = 0; i < SYNC_COMMITTEE_HEIGHT; i++) builder.connect_hash256(verify_sync_committe_target.new_sync_committee_ii_branch[i], p.new_sync_committee_ii_branch[i]);
   p.is_attested_from_next_period = find_sync_committee_target.is_attested_from_next_period;
+  // *** update validity ***   (targets.rs:589-598, 637-640)
+  builder.connect_hash256(finalized_slot_connect.h256, p.finalized_slot);
+  builder.connect(update_validity_target.cur_slot, find_sync_committee_target.cur_slot.value);
+  builder.connect(update_validity_target.finalized_slot, finalized_slot_connect.value);
+  builder.connect(update_validity_target.participation, p.participation);
   // *** contract state ***
   builder.connect_hash256(contract_state_target.cur_state, p.cur_state);
   builder.connect_hash256(contract_state_target.new_state, p.new_state);
@@ -344,8 +384,7 @@ void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], c
                       const uint8_t cur_sync_committee_i[32], const uint8_t cur_sync_committee_ii[32], const uint8_t new_sync_committee_i[32],
                       const uint8_t new_sync_committee_ii[32], const std::vector<bool> &sync_committee_bits,
                       const uint8_t new_sync_committee_ii_branch[5][32], const uint8_t sync_committee_pubkeys[][48],
-                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], bool is_attested_from_next_period,
-                      const ProofTarget &target) {
+                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], const ProofTarget &target) {
   uint8_t tmp[32];
   witness.set_hash256_target(target.attested_header_root, attested_header_root);
   witness.set_hash256_target(target.domain, domain);
@@ -376,7 +415,6 @@ void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], c
     witness.set_target_arr(target.sync_committee.pubkeys[i], std::vector<F>(sync_committee_pubkeys[i], sync_committee_pubkeys[i] + G1_PUBKEY_SIZE));
   witness.set_target_arr(target.sync_committee.aggregate_pubkey, std::vector<F>(sync_committee_aggregate, sync_committee_aggregate + G1_PUBKEY_SIZE));
   witness.set_target_arr(target.signature_bytes, std::vector<F>(signature, signature + 96));
-  witness.set_bool_target(target.is_attested_from_next_period, is_attested_from_next_period);
 }
 
 }  // namespace lc

@@ -29,9 +29,24 @@ struct ContractStateTarget {
       new_sync_committee_i, new_sync_committee_ii;
 };
 
-struct FindSyncCommitteeTarget {
+constexpr size_t FINALITY_THRESHOLD = 342;      // src/targets.rs:29
+constexpr size_t N_SLOTS_PER_PERIOD = 8192;     // src/targets.rs:30
+// src/utils.rs:93-113 BigUintHash256ConnectTarget for a u64: the Hash256Target of an SSZ uint64 (32 bytes, little endian,
+// read as 8 big-endian u32 limbs) tied bit by bit to the integer it encodes.  The reference keeps the integer as a
+// 256-bit BigUintTarget; here it is one field element, the 192 upper bits of the encoding are constrained to zero and
+// bit 63 as well (value < 2^63 < p), which every SSZ slot satisfies.
+struct SlotConnectTarget {
+  Hash256Target h256;
+  Target value;
+  std::vector<BoolTarget> bits;  // 64, little endian
+};
+struct FindSyncCommitteeTarget {  // src/targets.rs:37-45
+  SlotConnectTarget attested_slot, cur_slot;
   BoolTarget is_attested_from_next_period;
   Hash256Target cur_sync_committee_i, cur_sync_committee_ii, sync_committee_for_attested_slot;
+};
+struct UpdateValidityTarget {  // src/targets.rs:64-69
+  Target cur_slot, finalized_slot, participation;
 };
 struct VerifySyncCommitteeTarget {
   BoolTarget is_attested_from_next_period;
@@ -50,8 +65,8 @@ struct ProofTarget {
   std::vector<Hash256Target> new_sync_committee_ii_branch;
   SyncCommitteeTarget sync_committee;
   std::array<Target, 96> signature_bytes;
-  BoolTarget is_attested_from_next_period;  // witness of the stubbed period arithmetic (find_sync_committee)
-  Target participation;                      // sum of the sync committee bits (update_validity's threshold is stubbed)
+  BoolTarget is_attested_from_next_period;  // derived in-circuit by find_sync_committee
+  Target participation;                      // sum of the sync committee bits, compared with FINALITY_THRESHOLD by update_validity
 };
 
 std::vector<Hash256Target> compute_next_layer(CircuitBuilder &builder, size_t layer_size, const std::vector<Hash256Target> &prev_layer);
@@ -74,11 +89,14 @@ void set_beacon_block_header_target(PartialWitness &witness, const uint8_t heade
                                     const BeaconBlockHeaderTarget &target);
 ContractStateTarget add_virtual_contract_state_target(CircuitBuilder &builder);
 VerifySyncCommitteeTarget add_virtual_verify_sync_committe_target(CircuitBuilder &builder);
-// STUB: the reference derives is_attested_from_next_period from BigUint slot arithmetic (slot / 8192); here it is a
-// boolean witness and only the committee selection is constrained
+SlotConnectTarget add_virtual_biguint_hash256_connect_target(CircuitBuilder &builder);
+// src/targets.rs:184-235: periods = slot / 8192 from the slots' bits; the attested period must be the current one or the
+// next (d = attested_period - cur_period is constrained boolean: the reference's two is_equal + or + assert), the signing
+// committee is i for the current period and ii for the next
 FindSyncCommitteeTarget add_virtual_find_sync_committee_target(CircuitBuilder &builder);
-// src/targets.rs:391-683 with the recursive BLS verifier (:468-482), find_sync_committee's period arithmetic (:184-235),
-// update_validity (:304-332) and the BigUint<->Hash256 slot connections (:646-659) stubbed: BASELINE configs[2]
+// src/targets.rs:304-332: cur_slot <= finalized_slot and participation > FINALITY_THRESHOLD (range checks of the differences)
+UpdateValidityTarget add_virtual_update_validity_target(CircuitBuilder &builder);
+// src/targets.rs:391-683 with only the recursive BLS verifier (:468-482) stubbed: BASELINE configs[2]
 ProofTarget add_virtual_proof_target(CircuitBuilder &builder);
 // src/targets.rs:771-898 (same argument order; the BLS proof / verifier data arguments are dropped)
 void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], const uint8_t domain[32], uint64_t attested_slot,
@@ -90,7 +108,6 @@ void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], c
                       const uint8_t cur_sync_committee_i[32], const uint8_t cur_sync_committee_ii[32], const uint8_t new_sync_committee_i[32],
                       const uint8_t new_sync_committee_ii[32], const std::vector<bool> &sync_committee_bits,
                       const uint8_t new_sync_committee_ii_branch[5][32], const uint8_t sync_committee_pubkeys[][48],
-                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], bool is_attested_from_next_period,
-                      const ProofTarget &target);
+                      const uint8_t sync_committee_aggregate[48], const uint8_t signature[96], const ProofTarget &target);
 
 }  // namespace lc

@@ -31,7 +31,7 @@ extern const uint32_t SHA_IV[8];
 
 // one generator step, evaluated in creation order by generate_witness
 struct Op {
-  enum Kind { CONST, ARITH, SHA } kind;
+  enum Kind { CONST, ARITH, SHA, BITS } kind;  // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
   uint32_t out = 0, x = 0, y = 0, z = 0;  // CONST: out ; ARITH: x, y, z -> out
   F c0 = 0, c1 = 0;                        // CONST: c0 = value
   // SHA: message words in[16] -> digest out8[8]; internal words by row

@@ -90,6 +90,10 @@ class CircuitBuilder {
   BoolTarget not_(BoolTarget b);                         // builder.not(b) = 1 - b
   Target select(BoolTarget b, Target x, Target y);       // builder._if / select: b ? x : y
   void assert_bool(BoolTarget b);                        // b * b = b
+  // builder.split_le(x, nbits): little-endian bits of x, each constrained boolean, recomposition constrained equal to x
+  // (so x < 2^nbits is enforced); le_sum: sum of bits[first .. first + count) * 2^i
+  std::vector<BoolTarget> split_le(Target x, size_t nbits);
+  Target le_sum(const std::vector<BoolTarget> &bits, size_t first = 0, size_t count = (size_t)-1);
   void connect(Target a, Target b);
   void connect_u32(U32Target a, U32Target b) { connect(a.t, b.t); }
   void connect_hash256(const Hash256Target &a, const Hash256Target &b) { for (int i = 0; i < 8; i++) connect(a[i].t, b[i].t); }

@@ -287,7 +287,6 @@ LightClientStep set_light_client_step(PartialWitness &witness, const ProofTarget
   st.cur_state = contract_state_root(cur_slot, cur_header, cur_i, cur_ii);
   st.new_state = contract_state_root(cur.finalized_header.slot, st.finalized_header_root, new_i, new_ii);
   const uint64_t attested_period = cur.attested_header.slot / 8192, cur_period = cur_slot / 8192;
-  if (attested_period != cur_period && attested_period != cur_period + 1) throw std::runtime_error("light client step: attested slot is not in the current or the next period");
   st.is_attested_from_next_period = attested_period == cur_period + 1;
   for (bool b : cur.sync_aggregate.sync_committee_bits) st.participation += b;
   uint8_t finality_branch[6][32], sc_branch[5][32];
@@ -303,7 +302,7 @@ LightClientStep set_light_client_step(PartialWitness &witness, const ProofTarget
                    cur.finalized_header.body_root.data(), finality_branch, st.cur_state.data(), st.new_state.data(), cur_slot, cur_header.data(),
                    cur_i.data(), cur_ii.data(), new_i.data(), new_ii.data(), cur.sync_aggregate.sync_committee_bits, sc_branch,
                    reinterpret_cast<const uint8_t(*)[G1_PUBKEY_SIZE]>(pubkeys.data()), prev.next_sync_committee.aggregate_pubkey.data(),
-                   cur.sync_aggregate.sync_committee_signature.data(), st.is_attested_from_next_period, target);
+                   cur.sync_aggregate.sync_committee_signature.data(), target);
   return st;
 }
 

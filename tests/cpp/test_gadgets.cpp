@@ -5,7 +5,7 @@
 //   src/unit_tests.rs:37-246              test_signing_root, test_beacon_block_header, test_verify_finality_branch,
 //                                         test_contract_state                   (BASELINE configs[0])
 //   src/main.rs:84-233                    test_light_client_update: updates 633 -> 634 through add_virtual_proof_target /
-//                                         set_proof_target (BASELINE configs[2], BLS verifier + BigUint checks stubbed)
+//                                         set_proof_target (BASELINE configs[2], BLS verifier stubbed)
 //   src/unit_tests.rs:288-620             sync-committee branch (index 55, height 5): one positive, one #[should_panic]
 // usage: test_gadgets <cpu|gpu> <test name | all>
 //   cpu: witness generation + row-wise constraint check + oracle prove/verify (the oracle is the checker; the product
@@ -257,7 +257,8 @@ static void test_read_u32_be_public_input() {
 // main.rs takes them from tree_hash_root(); the domain is compute_domain(DOMAIN_SYNC_COMMITTEE, Bellatrix fork
 // version, mainnet genesis_validators_root) -- with the BLS verifier stubbed any 32 bytes keep the circuit consistent.
 static void sha2(const uint8_t *l, const uint8_t *r, uint8_t *out) { orc_sha256_two_to_one(l, r, out); }
-static void light_client_update(bool corrupt_state_root) {
+enum LcVariant { LC_OK, LC_BAD_STATE_ROOT, LC_LOW_PARTICIPATION };
+static void light_client_update(LcVariant variant) {
   CircuitBuilder builder(CircuitConfig::standard_recursion_config());
   ProofTarget target = add_virtual_proof_target(builder);
   for (auto &limb : target.cur_state) builder.register_public_input(limb.t);  // src/main.rs:180-187
@@ -281,16 +282,20 @@ static void light_client_update(bool corrupt_state_root) {
   orc_ssz_sync_committee_root(&LC634__NEXT_SYNC_COMMITTEE_PUBKEYS[0][0], LC634__NEXT_SYNC_COMMITTEE_AGGREGATE, new_ii);
   const uint8_t *cur_i = LC633__NEXT_SYNC_COMMITTEE_BRANCH[0], *new_i = LC634__NEXT_SYNC_COMMITTEE_BRANCH[0];
   if (memcmp(cur_ii, new_i, 32) != 0) throw std::runtime_error("fixture: root(633.next_sync_committee) != 634.next_sync_committee_branch[0]");
-  orc_contract_state_root(LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii, cur_state);
+  const uint64_t cur_slot = LC633__FINALIZED_SLOT;
+  orc_contract_state_root(cur_slot, cur_header, cur_i, cur_ii, cur_state);
   orc_contract_state_root(LC634__FINALIZED_SLOT, finalized_header_root, new_i, new_ii, new_state);
   std::vector<bool> bits(SYNC_COMMITTEE_SIZE);
   size_t participation = 0;
-  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) { bits[i] = (LC634__SYNC_COMMITTEE_BITS[i / 8] >> (i % 8)) & 1; participation += bits[i]; }
-  const bool next_period = LC634__ATTESTED_SLOT / 8192 == LC633__FINALIZED_SLOT / 8192 + 1;  // find_sync_committee's stubbed arithmetic
-  if (!next_period) throw std::runtime_error("fixture: attested slot is expected to be in the period after the current state");
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) {
+    bits[i] = (LC634__SYNC_COMMITTEE_BITS[i / 8] >> (i % 8)) & 1;
+    if (variant == LC_LOW_PARTICIPATION && participation >= FINALITY_THRESHOLD) bits[i] = false;  // exactly 342 signers: not enough
+    participation += bits[i];
+  }
+  if (LC634__ATTESTED_SLOT / 8192 != LC633__FINALIZED_SLOT / 8192 + 1) throw std::runtime_error("fixture: attested slot is expected to be in the period after the current state");
   uint8_t attested_state_root[32];
   memcpy(attested_state_root, LC634__ATTESTED_STATE_ROOT, 32);
-  if (corrupt_state_root) attested_state_root[5] ^= 1;  // breaks the header root, finality branch and committee branch
+  if (variant == LC_BAD_STATE_ROOT) attested_state_root[5] ^= 1;  // breaks the header root, finality branch and committee branch
 
   PartialWitness pw;
   set_proof_target(pw, signing_root, DOMAIN, LC634__ATTESTED_SLOT, LC634__ATTESTED_PROPOSER_INDEX, attested_header_root,
@@ -298,7 +303,7 @@ static void light_client_update(bool corrupt_state_root) {
                    LC634__FINALIZED_PROPOSER_INDEX, finalized_header_root, LC634__FINALIZED_PARENT_ROOT, LC634__FINALIZED_STATE_ROOT,
                    LC634__FINALIZED_BODY_ROOT, LC634__FINALITY_BRANCH, cur_state, new_state, LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii,
                    new_i, new_ii, bits, LC634__NEXT_SYNC_COMMITTEE_BRANCH, LC633__NEXT_SYNC_COMMITTEE_PUBKEYS,
-                   LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC634__SYNC_COMMITTEE_SIGNATURE, next_period, target);
+                   LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC634__SYNC_COMMITTEE_SIGNATURE, target);
   printf("light-client update 633 -> 634: participation %zu / 512, attested slot %llu (period %llu), state slot %llu -> %llu\n", participation,
          (unsigned long long)LC634__ATTESTED_SLOT, (unsigned long long)(LC634__ATTESTED_SLOT / 8192), (unsigned long long)LC633__FINALIZED_SLOT,
          (unsigned long long)LC634__FINALIZED_SLOT);
@@ -306,8 +311,63 @@ static void light_client_update(bool corrupt_state_root) {
   try { prove_and_verify(*data, pw); } catch (...) { g_skip_oracle_prove = false; throw; }
   g_skip_oracle_prove = false;
 }
-static void test_light_client_update() { light_client_update(false); }
-static void test_light_client_update_bad_state_root_panics() { light_client_update(true); }
+static void test_light_client_update() { light_client_update(LC_OK); }
+static void test_light_client_update_bad_state_root_panics() { light_client_update(LC_BAD_STATE_ROOT); }
+// src/targets.rs:304-332 update_validity and :184-235 find_sync_committee reject what they are there to reject
+static void test_light_client_update_low_participation_panics() { light_client_update(LC_LOW_PARTICIPATION); }
+
+// ---- the slot / participation gadgets on their own (src/targets.rs:184-235, :304-332, src/utils.rs:93-113)
+static void slot_h256(uint64_t slot, uint8_t out[32]) { memset(out, 0, 32); for (int i = 0; i < 8; i++) out[i] = (uint8_t)(slot >> (8 * i)); }
+static void find_sync_committee(uint64_t cur_slot, uint64_t attested_slot, bool expect_next) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  FindSyncCommitteeTarget t = add_virtual_find_sync_committee_target(builder);
+  Hash256Target expected = builder.add_virtual_hash256_target();
+  builder.connect_hash256(t.sync_committee_for_attested_slot, expected);
+  builder.register_public_input(t.is_attested_from_next_period.target);
+  builder.register_public_input(t.cur_slot.value);
+  auto data = builder.build();
+  PartialWitness pw;
+  uint8_t b[32];
+  slot_h256(cur_slot, b); pw.set_hash256_target(t.cur_slot.h256, b);
+  slot_h256(attested_slot, b); pw.set_hash256_target(t.attested_slot.h256, b);
+  pw.set_hash256_target(t.cur_sync_committee_i, CONTRACT_STATE__CUR_SYNC_COMMITTEE_I);
+  pw.set_hash256_target(t.cur_sync_committee_ii, CONTRACT_STATE__CUR_SYNC_COMMITTEE_II);
+  pw.set_hash256_target(expected, expect_next ? CONTRACT_STATE__CUR_SYNC_COMMITTEE_II : CONTRACT_STATE__CUR_SYNC_COMMITTEE_I);
+  std::vector<uint64_t> wires;
+  std::vector<F> pis;
+  data->generate_witness(pw, wires, pis);
+  if (pis[0] != (F)expect_next || pis[1] != cur_slot) throw std::runtime_error("find_sync_committee: wrong period flag or slot value");
+  prove_and_verify(*data, pw);
+}
+static void test_find_sync_committee_current_period() { find_sync_committee(LC633__FINALIZED_SLOT, LC633__FINALIZED_SLOT + 100, false); }
+static void test_find_sync_committee_next_period() { find_sync_committee(LC633__FINALIZED_SLOT, LC634__ATTESTED_SLOT, true); }
+static void test_find_sync_committee_stale_period_panics() { find_sync_committee(LC633__FINALIZED_SLOT - 8192, LC634__ATTESTED_SLOT, true); }
+static void test_find_sync_committee_previous_period_panics() { find_sync_committee(LC634__ATTESTED_SLOT, LC633__FINALIZED_SLOT, false); }
+static void test_slot_connect_rejects_wide_encoding_panics() {  // byte 8 of the 32-byte slot encoding is not zero
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  SlotConnectTarget t = add_virtual_biguint_hash256_connect_target(builder);
+  auto data = builder.build();
+  PartialWitness pw;
+  uint8_t b[32];
+  slot_h256(5, b);
+  b[8] = 1;
+  pw.set_hash256_target(t.h256, b);
+  prove_and_verify(*data, pw);
+}
+static void update_validity(uint64_t cur_slot, uint64_t finalized_slot, uint64_t participation) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  UpdateValidityTarget t = add_virtual_update_validity_target(builder);
+  auto data = builder.build();
+  PartialWitness pw;
+  pw.set_target(t.cur_slot, cur_slot);
+  pw.set_target(t.finalized_slot, finalized_slot);
+  pw.set_target(t.participation, participation);
+  prove_and_verify(*data, pw);
+}
+static void test_update_validity() { update_validity(LC633__FINALIZED_SLOT, LC634__FINALIZED_SLOT, 428); }
+static void test_update_validity_equal_slots_and_343() { update_validity(7, 7, FINALITY_THRESHOLD + 1); }
+static void test_update_validity_finalized_before_current_panics() { update_validity(LC634__FINALIZED_SLOT, LC633__FINALIZED_SLOT, 428); }
+static void test_update_validity_threshold_not_exceeded_panics() { update_validity(1, 2, FINALITY_THRESHOLD); }
 
 struct TestCase { const char *name; std::function<void()> fn; bool should_panic; };
 static const TestCase TESTS[] = {
@@ -326,6 +386,16 @@ static const TestCase TESTS[] = {
     {"test_ssz_sync_committee", test_ssz_sync_committee, false},
     {"test_light_client_update", test_light_client_update, false},
     {"test_light_client_update_bad_state_root_panics", test_light_client_update_bad_state_root_panics, true},
+    {"test_light_client_update_low_participation_panics", test_light_client_update_low_participation_panics, true},
+    {"test_find_sync_committee_current_period", test_find_sync_committee_current_period, false},
+    {"test_find_sync_committee_next_period", test_find_sync_committee_next_period, false},
+    {"test_find_sync_committee_stale_period_panics", test_find_sync_committee_stale_period_panics, true},
+    {"test_find_sync_committee_previous_period_panics", test_find_sync_committee_previous_period_panics, true},
+    {"test_slot_connect_rejects_wide_encoding_panics", test_slot_connect_rejects_wide_encoding_panics, true},
+    {"test_update_validity", test_update_validity, false},
+    {"test_update_validity_equal_slots_and_343", test_update_validity_equal_slots_and_343, false},
+    {"test_update_validity_finalized_before_current_panics", test_update_validity_finalized_before_current_panics, true},
+    {"test_update_validity_threshold_not_exceeded_panics", test_update_validity_threshold_not_exceeded_panics, true},
 };
 
 int main(int argc, char **argv) {

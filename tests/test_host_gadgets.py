@@ -10,7 +10,11 @@ CPU_TESTS = [
     "test_merkle_root_wrong_root_panics", "test_signing_root", "test_beacon_block_header", "test_verify_finality_branch",
     "test_contract_state", "test_verify_sync_committee_branch", "test_verify_sync_committee_branch_panics",
     "test_read_u32_be_public_input", "test_ssz_sync_committee", "test_light_client_update",
-    "test_light_client_update_bad_state_root_panics",
+    "test_light_client_update_bad_state_root_panics", "test_light_client_update_low_participation_panics",
+    "test_find_sync_committee_current_period", "test_find_sync_committee_next_period",
+    "test_find_sync_committee_stale_period_panics", "test_find_sync_committee_previous_period_panics",
+    "test_slot_connect_rejects_wide_encoding_panics", "test_update_validity", "test_update_validity_equal_slots_and_343",
+    "test_update_validity_finalized_before_current_panics", "test_update_validity_threshold_not_exceeded_panics",
 ]
 
 
