@@ -660,6 +660,17 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
       }
     }
   }
+  // Shares must SUM to the proof (RCCL has no bitwise reductions): the words every rank computes identically (openings,
+  // FRI caps and layers, final polynomial, PoW witness) are contributed by the rank that holds leaf block 0 only.
+  if (c->sharded() && c->bf != 0) {
+    std::vector<u64> keep(proof + L.queries, proof + L.queries + (size_t)Qn * L.query_words);
+    memset(proof + L.op_constants, 0, (L.total - L.op_constants) * 8);
+    for (u32 q = 0; q < Qn; q++) {
+      if (!mine[q]) continue;
+      const size_t init_words = L.q_step_off[0] ? L.q_step_off[0] : L.query_words;  // the four initial-tree openings come first
+      memcpy(proof + L.queries + (size_t)q * L.query_words, keep.data() + (size_t)q * L.query_words, init_words * 8);
+    }
+  }
   return LCP2_OK;
 }
 }  // namespace

@@ -103,10 +103,10 @@ class GpuOps:
 # One whole proof sharded by LDE coset (include/lcp2.h "one proof sharded over the GPUs of a node").
 class ShardedProver:
     """Rank `rank` of `world` in a coset-sharded proof.  Every rank holds the whole witness and runs the same sequence of
-    seams on its own leaf blocks; results are shares that a bitwise-OR all-reduce assembles (caps, the proof array) plus one
-    bulk all-reduce of the quotient values.  `comm` supplies the two collectives:
-        comm.or_host(numpy uint64 array) -> numpy uint64 array       (tiny: 512-byte caps, the proof array)
-        comm.or_device(device pointer, uint64 words)                  (in place; 2 * 8n words: RCCL over xGMI)
+    seams on its own leaf blocks; results are shares that a SUM all-reduce assembles (caps, the proof array; uint64 wrap-around,
+    the shares are disjoint) plus one bulk all-reduce of the quotient values.  `comm` supplies the two collectives:
+        comm.sum_host(numpy uint64 array) -> numpy uint64 array      (tiny: 512-byte caps, the proof array)
+        comm.sum_device(device pointer, uint64 words)                 (in place; 2 * 8n words: RCCL over xGMI)
     so that the same orchestration runs over torch.distributed (TorchComm) and, in the single-GPU tests, over ranks that are
     stepped in lockstep inside one process."""
 
@@ -118,7 +118,7 @@ class ShardedProver:
         self.cap_share = self.data.digest()[1]
 
     def finish_build(self):
-        self.data.set_constants_cap(self.comm.or_host(self.cap_share))
+        self.data.set_constants_cap(self.comm.sum_host(self.cap_share))
         self.digest = self.data.digest()[0]
 
     # the proof as a generator of exchange points, so that a test can interleave several ranks in one process
@@ -131,23 +131,24 @@ class ShardedProver:
         ch.observe(self.digest)
         ch.observe(b.hash_no_pad(pis))
         share = d.commit_wires(wires, mem)
-        proof[0:capw] = (yield ("or_host", share)).ravel()
+        proof[0:capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[0:capw])
         betas, gammas = ch.get(p.num_challenges), ch.get(p.num_challenges)
         share = d.perm_zs(betas, gammas)
-        proof[capw:2 * capw] = (yield ("or_host", share)).ravel()
+        proof[capw:2 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[capw:2 * capw])
         alphas = ch.get(p.num_challenges)
         d.quotient_values(alphas, pis)
-        yield ("or_device",) + d.quotient_buffer()
+        yield ("sum_device",) + d.quotient_buffer()
         share = d.quotient_commit()
-        proof[2 * capw:3 * capw] = (yield ("or_host", share)).ravel()
+        proof[2 * capw:3 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[2 * capw:3 * capw])
         zeta = ch.get(2)
         caps = proof[:3 * capw].copy()
-        d.fri_open(zeta, ch.state, proof)
+        d.fri_open(zeta, ch.state, proof)  # writes the words after the caps: this rank's share of them
+        proof[:3 * capw] = 0
+        proof = (yield ("sum_host", proof))
         proof[:3 * capw] = caps
-        proof = (yield ("or_host", proof))
         self.proof = proof
         return
 
@@ -157,10 +158,10 @@ class ShardedProver:
         try:
             while True:
                 req = steps.send(reply)
-                if req[0] == "or_host":
-                    reply = self.comm.or_host(req[1])
+                if req[0] == "sum_host":
+                    reply = self.comm.sum_host(req[1])
                 else:
-                    self.comm.or_device(req[1], req[2])
+                    self.comm.sum_device(req[1], req[2])
                     reply = None
         except StopIteration:
             return self.proof
@@ -172,18 +173,18 @@ class TorchComm:
     def __init__(self, dist, device=None, ctx=None):
         self.dist, self.device, self.ctx = dist, device, ctx
 
-    def or_host(self, arr):
+    def sum_host(self, arr):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
         if self.device is not None:
             t = t.to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.BOR)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # two's-complement wrap-around = uint64 addition
         return t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
 
-    def or_device(self, ptr, words):
+    def sum_device(self, ptr, words):
         import torch
         t = torch.empty(words, dtype=torch.int64, device=self.device)  # staging tensor: two device copies (< 1 ms at 537 MB)
         self.ctx.buffer_copy(t.data_ptr(), ptr, words)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.BOR)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         self.ctx.buffer_copy(ptr, t.data_ptr(), words)

@@ -276,13 +276,14 @@ int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* 
  * (block_count a power of two dividing 2^rate_bits, block_first aligned to it, cap_height >= rate_bits so that a block is
  * whole cap subtrees: no cross-GPU hashing).  Every rank gets the whole witness and runs the same call sequence as the
  * seams above; what a rank returns is its SHARE of the result - its own cap entries / query answers at their global
- * position, zeros elsewhere, replicated parts identical on every rank - so one bitwise-OR all-reduce of each cap and of
- * the proof array assembles the result.  The only bulk exchange is the quotient values (num_challenges * 8n words): each
- * rank fills its blocks of lcp2_quotient_buffer (zeros elsewhere), the caller sum-/OR-all-reduces that buffer in place
- * over RCCL, then every rank calls lcp2_quotient_commit.  Order per proof:
- *   lcp2_commit_wires -> OR caps -> lcp2_perm_zs -> OR caps -> lcp2_quotient_values -> all-reduce buffer ->
- *   lcp2_quotient_commit -> OR caps -> lcp2_fri_open -> OR proofs.
- * At build: lcp2_circuit_create_sharded, lcp2_circuit_digest (cap share; digest not valid yet), OR the cap,
+ * position, zeros elsewhere; the parts of lcp2_fri_open's output that every rank computes identically come from the rank
+ * holding block 0 only - so one SUM all-reduce (uint64 wrap-around; RCCL has no bitwise reductions) of each cap and of
+ * the proof words lcp2_fri_open wrote assembles the result.  The only bulk exchange is the quotient values
+ * (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer (zeros elsewhere), the caller
+ * sum-all-reduces that buffer in place over RCCL, then every rank calls lcp2_quotient_commit.  Order per proof:
+ *   lcp2_commit_wires -> sum caps -> lcp2_perm_zs -> sum caps -> lcp2_quotient_values -> all-reduce buffer ->
+ *   lcp2_quotient_commit -> sum caps -> lcp2_fri_open -> sum the words from the openings on.
+ * At build: lcp2_circuit_create_sharded, lcp2_circuit_digest (cap share; digest not valid yet), sum the cap,
  * lcp2_circuit_set_constants_cap.  lcp2_prove / lcp2_quotient refuse a sharded circuit. */
 int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, uint32_t block_first, uint32_t block_count,
                                 lcp2_circuit **out);

@@ -1,6 +1,6 @@
 """One proof sharded by LDE coset over 2 / 4 / 8 ranks (BASELINE configs[3]; include/lcp2.h "one proof sharded
 over the GPUs of a node").  On the single test GPU the ranks are separate sharded circuit handles stepped in lockstep in
-one process, the collectives are emulated on the host; the assembled proof must equal the single-GPU proof word for word
+one process, the collectives are emulated on the host (uint64 sums of disjoint shares); the assembled proof must equal the single-GPU proof word for word
 (which itself equals the oracle's, test_gpu_prover.py).  The torch.distributed collectives are covered on CPU with gloo."""
 import os
 import subprocess
@@ -18,17 +18,17 @@ class LockstepComm:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def or_host_all(self, arrays):
+    def sum_host_all(self, arrays):
         acc = np.zeros_like(arrays[0])
         for a in arrays:
-            acc |= a
+            acc += a  # uint64 wrap-around, as the int64 SUM all-reduce does
         return acc
 
-    def or_device_all(self, bufs):
+    def sum_device_all(self, bufs):
         acc = None
         for ptr, words in bufs:
             v = self.ctx.buffer_read(ptr, words)
-            acc = v if acc is None else acc | v
+            acc = v if acc is None else acc + v
         for ptr, words in bufs:
             self.ctx.buffer_write(ptr, acc)
 
@@ -36,9 +36,9 @@ class LockstepComm:
 def _run_lockstep(m, ctx, circ, wires, pis, world):
     comm = LockstepComm(ctx)
     ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
-    cap = comm.or_host_all([r.cap_share for r in ranks])
+    cap = comm.sum_host_all([r.cap_share for r in ranks])
     for r in ranks:
-        r.comm = type("C", (), {"or_host": staticmethod(lambda a, cap=cap: cap)})()
+        r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
         r.finish_build()
     gens = [r.prove_steps(wires, pis) for r in ranks]
     replies = [None] * world
@@ -52,11 +52,11 @@ def _run_lockstep(m, ctx, circ, wires, pis, world):
         if all(q is None for q in reqs):
             break
         assert all(q is not None and q[0] == reqs[0][0] for q in reqs), "ranks diverged"
-        if reqs[0][0] == "or_host":
-            merged = comm.or_host_all([q[1] for q in reqs])
+        if reqs[0][0] == "sum_host":
+            merged = comm.sum_host_all([q[1] for q in reqs])
             replies = [merged.copy() for _ in range(world)]
         else:
-            comm.or_device_all([(q[1], q[2]) for q in reqs])
+            comm.sum_device_all([(q[1], q[2]) for q in reqs])
             replies = [None] * world
     return ranks
 
@@ -139,22 +139,22 @@ comm = m.parallel.TorchComm(dist)
 # cap shares: rank r owns entries [8r, 8r + 8) of a 16-entry cap
 share = np.zeros((16, 4), dtype=np.uint64)
 share[8 * rank:8 * rank + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) + np.uint64(1000 * (rank + 1)) + (np.uint64(1) << np.uint64(63))
-full = comm.or_host(share)
+full = comm.sum_host(share)
 want = np.zeros((16, 4), dtype=np.uint64)
 for r in range(2):
     want[8 * r:8 * r + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) + np.uint64(1000 * (r + 1)) + (np.uint64(1) << np.uint64(63))
 assert (full == want).all() and full.dtype == np.uint64
-# replicated words stay what they are
-rep = np.array([5, 2**64 - 1, 0, 77], dtype=np.uint64)
-assert (comm.or_host(rep) == rep).all()
+# replicated words come from rank 0 only (lcp2_fri_open zeroes them on the other ranks): full 64-bit values survive the int64 sum
+rep = np.array([5, 2**64 - 1, 0, 2**63 + 77], dtype=np.uint64)
+assert (comm.sum_host(rep if rank == 0 else np.zeros_like(rep)) == rep).all()
 assert m.parallel.block_range(rank, 2) == (4 * rank, 4)
 dist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_torch_comm_or_allreduce_gloo(tmp_path):
-    """world_size-2 gloo: the OR all-reduce that assembles caps and the proof from the ranks' shares (full 64-bit words)"""
+def test_torch_comm_sum_allreduce_gloo(tmp_path):
+    """world_size-2 gloo: the SUM all-reduce (int64 wrap-around) that assembles caps and the proof from the ranks' shares"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
     port = str(29500 + os.getpid() % 2000)

@@ -4,7 +4,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_proof_demo.py [--degree-bits 22]
 
 Every rank builds the same synthetic circuit and witness (same seed), holds 8/N leaf blocks of every LDE / Merkle tree and
-proves through eth-lc-plonky2_amd/parallel.py::ShardedProver: four 512-byte OR all-reduces, one OR all-reduce of the proof
+proves through eth-lc-plonky2_amd/parallel.py::ShardedProver: four 512-byte sum all-reduces, one sum all-reduce of the proof
 array and one bulk all-reduce of the quotient values (2 * 8n words) over RCCL.  Rank 0 verifies the assembled proof and
 prints the wall time per proof.  With N = 1 the same code path runs with one rank holding all 8 blocks (the only case a
 one-GPU box can run; the multi-rank data flow is covered by tests/test_sharded_prover.py with the ranks in lockstep on
@@ -18,10 +18,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 class _Solo:  # N = 1: the collectives are the identity
-    def or_host(self, a):
+    def sum_host(self, a):
         return a
 
-    def or_device(self, ptr, words):
+    def sum_device(self, ptr, words):
         pass
 
 
