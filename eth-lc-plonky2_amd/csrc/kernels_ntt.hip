@@ -10,7 +10,18 @@ template <bool INV>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassParams p) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   NttPass pass{p};
-  const u32 tid = threadIdx.x, wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z + p.z_base;
+  const u32 tid = threadIdx.x;
+  u32 wg = blockIdx.x, col = blockIdx.y, z = blockIdx.z + p.z_base;
+  if (p.xcd_group) {
+    // XCD-aware mapping (speed only): blocks b and b + 8 share an XCD and its L2.  The 2^zbits coset transforms of an LDE read
+    // the same coefficient slab, so the j-th block of XCD label x takes coset j % nz of slab (j / nz) * 8 + x: the slab is
+    // fetched from HBM once and the other cosets hit L2, instead of nz HBM reads spread over the launch.
+    const u32 lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), x = lin & 7, j = lin >> 3, nz = gridDim.z;
+    const u32 sc = (j / nz) * 8 + x;
+    z = j % nz + p.z_base;
+    wg = sc % gridDim.x;
+    col = sc / gridDim.x;
+  }
   pass.template load<INV>(lds, tid, NTT_THREADS, wg, col, z);
   __syncthreads();
   for (u32 si = 0; si < p.nsteps; si++) {

@@ -64,6 +64,7 @@ struct NttPassParams {
   u32 L, S, B, g_lo;                  // slab bits, run bits, group bits, bits below the group
   const u64 *group_tw;                // w_{2^B}^e (or its inverse), e < 2^B: step twiddles
   u64 wr[8];                          // w_16^k (or inverse), k < 8: constant twiddles of the register transforms
+  u32 xcd_group;                      // LDE first pass: the 2^zbits coset transforms of one slab run back to back on one XCD (kernels_ntt.hip)
   u32 nsteps;
   u32 step_plan;                      // stages per register step, 4 bits each, listed from the top bits of the group down
   TwoLevelTable tw;                   // w_{N_g}^e (or inverse); used when g_lo > 0

@@ -142,6 +142,8 @@ struct NttHost {
         wgs = 1u << (lg + lgcount - g.L);
         nz = 1;
       }
+      // first pass of a full LDE: group the cosets of a slab on one XCD when the block count allows the bijection
+      p.xcd_group = first && nz > 1 && ((u64)wgs * ncols) % 8 == 0 ? 1 : 0;
       be.launch_pass(false, p, wgs, ncols, nz);
     }
   }

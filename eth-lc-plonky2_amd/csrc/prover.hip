@@ -634,8 +634,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     }
     for (u32 l = 0; l < p.num_fri_layers; l++) {
       const u32 arity = 1u << p.fri_arity_bits[l];
-      u64 nvals = (n >> 0);  // recomputed below
-      nvals = N;
+      u64 nvals = N;  // values of layer l: N >> (arity bits of the layers before it)
       for (u32 k = 0; k < l; k++) nvals >>= p.fri_arity_bits[k];
       f_leaf[l] = pos; pos += (size_t)Qn * 2 * arity;
       f_sib[l] = pos; pos += (size_t)Qn * L.q_step_sib[l] * 4;
