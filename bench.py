@@ -108,16 +108,22 @@ def cpu_baseline(sample_bits, degree_bits):
         assert oc.verify(proof, pis) == 0
         return dt
 
-    dt = timed()
     scale = float(1 << (degree_bits - sample_bits))
-    out = {"value": 3600.0 / (dt * scale), "unit": "proofs/hr", "cores": threads, "kind": "port",
-           "sample": "oracle prove() of the same gate set at 2^%d rows: %.2f s on %d OpenMP threads, scaled x%d (linear in rows) to 2^%d"
-                     % (sample_bits, dt, threads, int(scale), degree_bits)}
-    if omp is not None and threads > 32:  # the reference's published figure is for 32 vCPU (README.md:71): the same sample on 32 threads
-        omp.omp_set_num_threads(32)
-        dt32 = timed()
+
+    def entry(dt, nthreads):
+        return {"value": 3600.0 / (dt * scale), "unit": "proofs/hr", "cores": nthreads, "kind": "port",
+                "sample": "oracle prove() of the same gate set at 2^%d rows: %.2f s on %d OpenMP threads, scaled x%d (linear in rows) to 2^%d"
+                          % (sample_bits, dt, nthreads, int(scale), degree_bits)}
+
+    runs = [entry(timed(), threads)]
+    if omp is not None and threads > 32:  # the reference's published figure is for 32 vCPU (README.md:71); many-core hosts are also
+        omp.omp_set_num_threads(32)       # often faster on 32 threads than oversubscribed on all of them
+        runs.append(entry(timed(), 32))
         omp.omp_set_num_threads(threads)
-        out["at_32_threads"] = {"value": 3600.0 / (dt32 * scale), "unit": "proofs/hr", "cores": 32, "sample_seconds": dt32}
+    runs.sort(key=lambda e: -e["value"])
+    out = runs[0]  # the faster configuration is the baseline; the other one is kept beside it
+    if len(runs) > 1:
+        out["other_thread_count"] = {k: runs[1][k] for k in ("value", "unit", "cores", "sample")}
     return out
 
 
