@@ -112,8 +112,15 @@ u64 scan_scratch_words(u64 n, u32 batches) { return ((n + SCAN_BLOCK - 1) / SCAN
 // ------------------------------------------------------------------ K5: permutation argument on H
 // One thread per (row, challenge): the NCHUNK quotient-chunk products  prod_j num_j / den_j  and their product.
 __global__ __launch_bounds__(256) void k_perm_chunks(PermArgs a) {
-  u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u32 ch = blockIdx.y;
+  u32 rb = blockIdx.x, ch = blockIdx.y;
+  if (gridDim.x % 8 == 0) {
+    // XCD-aware mapping (speed only; blocks b and b + 8 share an XCD's L2): the challenges of one row block run back to back on
+    // one XCD, so the wires and sigmas they both read come from HBM once
+    const u32 lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7, j = lin >> 3;
+    ch = j % gridDim.y;
+    rb = (j / gridDim.y) * 8 + x;
+  }
+  u64 row = (u64)rb * blockDim.x + threadIdx.x;
   if (row >= a.n) return;
   const u64 beta = a.betas[ch], gamma = a.gammas[ch];
   u64 x = two_level(a.subgroup, row);
