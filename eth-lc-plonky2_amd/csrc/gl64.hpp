@@ -81,7 +81,8 @@ LCP2_HD u64 gl_reduce128_nc(u64 lo, u64 hi) {
 // wave-instruction, VOP2 carry ops through vcc ~2.7, v_mad_u64_u32 is a VOP3 op like any other.  Four v_mad_u64_u32
 // build the 128-bit product, the reduction runs on vcc carry chains: 17 instructions against hipcc's 27 for the
 // portable form.  hipcc pads nothing inside an asm string, so the wait states it emits itself for the same pairs
-// (VALU writes vcc -> carry-in reader: 1, -> e64 reader of vcc: 2) are written out as s_nop.
+// (VOP2 writes vcc -> carry-in reader v_addc / v_subb: 2, -> v_cndmask e32: 1, -> e64 reader of vcc: 2; after the VOP3
+// v_mad_u64_u32 carry-out: 2) are written out as s_nop.
 __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
   u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
   u32 c;
@@ -92,19 +93,19 @@ __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u3
   const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
   u32 lo1, hi0, hi1;  // 128-bit product = (hi1:hi0:lo1:p0)
   asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %2, vcc, %7, %8, vcc"
       : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
   u32 t0, t1, e;  // t = lo - hi1 ; on borrow t -= 2^32 - 1
   asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
       "s_nop 1\n\t"
       "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
       "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
       : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1) : "vcc");
   u64 t = ((u64)t1 << 32) | t0, r;  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
@@ -115,7 +116,7 @@ __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u3
       : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t) : "vcc");
   u32 q0 = (u32)r, q1 = (u32)(r >> 32);
   asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %1, vcc, 0, %3, vcc"
       : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
 }
@@ -133,19 +134,19 @@ __device__ __forceinline__ void gl_mul_halves_k(u32 a0, u32 a1, u32 b0, u32 b1, 
   const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
   u32 lo1, hi0, hi1;  // 128-bit product = (hi1:hi0:lo1:p0)
   asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %2, vcc, %7, %8, vcc"
       : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
   u32 t0, t1, e;  // t = lo - hi1 ; on borrow t -= 2^32 - 1
   asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
       "s_nop 0\n\t"
       "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
       "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
       : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1), "v"(km1) : "vcc");
   u64 t = ((u64)t1 << 32) | t0, r;  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
@@ -156,7 +157,7 @@ __device__ __forceinline__ void gl_mul_halves_k(u32 a0, u32 a1, u32 b0, u32 b1, 
       : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t), "v"(km1) : "vcc");
   u32 q0 = (u32)r, q1 = (u32)(r >> 32);
   asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_addc_co_u32 %1, vcc, 0, %3, vcc"
       : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
 }
