@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one wave64 instruction per 4 cycles per SIMD
 POSEIDON_VALU_INSTR = 8 * 1209 + 22 * 484 + 118  # census of the compiled permutation; SQ_INSTS_VALU measures 20 462
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench
 
 
 def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
