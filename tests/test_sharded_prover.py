@@ -157,7 +157,10 @@ def test_torch_comm_sum_allreduce_gloo(tmp_path):
     """world_size-2 gloo: the SUM all-reduce (int64 wrap-around) that assembles caps and the proof from the ranks' shares"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:  # a port the OS says is free (the other gloo tests do the same)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
