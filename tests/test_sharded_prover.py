@@ -148,13 +148,55 @@ assert (full == want).all() and full.dtype == np.uint64
 rep = np.array([5, 2**64 - 1, 0, 2**63 + 77], dtype=np.uint64)
 assert (comm.sum_host(rep if rank == 0 else np.zeros_like(rep)) == rep).all()
 assert m.parallel.block_range(rank, 2) == (4 * rank, 4)
+
+# ShardedProver.prove() end to end over real gloo collectives, with the per-rank compute replaced by a stand-in that returns
+# disjoint shares the way the C ABI does (own entries at their global position, zeros elsewhere; replicated words from rank 0)
+class FakeParams:
+    cap_height, num_challenges, rate_bits = 4, 2, 3
+class FakeCirc:
+    params = FakeParams()
+class FakeData:
+    proof_words = 3 * 64 + 40
+    def __init__(self, rank): self.rank, self.qbuf = rank, np.zeros(64, dtype=np.uint64)
+    def _share(self, tag):
+        c = np.zeros((16, 4), dtype=np.uint64)
+        c[8 * self.rank:8 * self.rank + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) * np.uint64(7) + np.uint64(tag + 100 * self.rank)
+        return c
+    def commit_wires(self, wires, mem): return self._share(1)
+    def perm_zs(self, betas, gammas): self.seen = [int(betas[0]), int(gammas[1])]; return self._share(2)
+    def quotient_values(self, alphas, pis): self.qbuf[32 * self.rank:32 * self.rank + 32] = np.arange(32, dtype=np.uint64) + np.uint64(int(alphas[0]) % 1000)
+    def quotient_buffer(self): return (id(self.qbuf), self.qbuf.size)
+    def quotient_commit(self): return self._share(3 + int(self.qbuf.sum() % 5))  # depends on the exchanged buffer
+    def fri_open(self, zeta, state, proof):
+        body = proof[3 * 64:]
+        if self.rank == 0: body[:20] = np.arange(20, dtype=np.uint64) + np.uint64(int(zeta[0]) % 97)   # replicated part
+        body[20 + 10 * self.rank:30 + 10 * self.rank] = np.uint64(555 + self.rank)                     # this rank's query answers
+class GlooComm(m.parallel.TorchComm):
+    def sum_device(self, ptr, words):  # the "device" buffer of the stand-in is a numpy array
+        buf = bufs[ptr]
+        buf[:] = self.sum_host(buf)
+sp = object.__new__(m.parallel.ShardedProver)
+sp.b, sp.circ, sp.rank, sp.world, sp.comm = m.binding, FakeCirc(), rank, 2, GlooComm(dist)
+sp.data = FakeData(rank)
+bufs = {id(sp.data.qbuf): sp.data.qbuf}
+sp.digest = np.arange(4, dtype=np.uint64)
+proof = sp.prove(None, np.array([3, 4], dtype=np.uint64))
+# both ranks hold the same assembled proof: caps complete, quotient buffer complete, replicated words once, every query answered
+gathered = [None, None]
+dist.all_gather_object(gathered, proof.tobytes())
+assert gathered[0] == gathered[1]
+caps = proof[:192].reshape(3, 16, 4)
+assert (caps[0] != 0).all() and (caps[1][8:] != 0).all() and (sp.data.qbuf != 0).sum() >= 62
+body = proof[192:]
+assert (body[20:30] == 555).all() and (body[30:40] == 556).all() and body[1] == body[0] + 1
 dist.destroy_process_group()
 print("ok", rank)
 """
 
 
 def test_torch_comm_sum_allreduce_gloo(tmp_path):
-    """world_size-2 gloo: the SUM all-reduce (int64 wrap-around) that assembles caps and the proof from the ranks' shares"""
+    """world_size-2 gloo: the SUM all-reduce (int64 wrap-around) that assembles caps and the proof from the ranks' shares, and
+    ShardedProver.prove() driven end to end over those collectives with a stand-in for the per-rank GPU compute"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
     import socket
