@@ -81,8 +81,9 @@ LCP2_HD u64 gl_reduce128_nc(u64 lo, u64 hi) {
 // wave-instruction, VOP2 carry ops through vcc ~2.7, v_mad_u64_u32 is a VOP3 op like any other.  Four v_mad_u64_u32
 // build the 128-bit product, the reduction runs on vcc carry chains: 17 instructions against hipcc's 27 for the
 // portable form.  hipcc pads nothing inside an asm string, so the wait states it emits itself for the same pairs
-// (VOP2 writes vcc -> carry-in reader v_addc / v_subb: 2, -> v_cndmask e32: 1, -> e64 reader of vcc: 2; after the VOP3
-// v_mad_u64_u32 carry-out: 2) are written out as s_nop.
+// (a VALU write of vcc / an SGPR -> any VALU read of it, carry-in of v_addc / v_subb and v_cndmask in either encoding alike:
+// 2 wait states) are written out as s_nop 1.  tools/check_hazards.py disassembles the built library and fails the build
+// if any such pair, hand-written or compiler-generated, has fewer.
 __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
   u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
   u32 c;
@@ -121,9 +122,8 @@ __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u3
       : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
 }
 // The same multiply with the select constants (1 and 2^32 - 1) held in VGPRs by the caller: v_cndmask_b32 is then a VOP2
-// instruction (~2.7 cycles per wave-instruction instead of ~4.4 for the VOP3 form with inline constants, tools/ubench) and
-// needs one wait state after a VOP2 vcc write instead of two.  Used where the two registers stay live across many
-// multiplies (the Poseidon permutation).
+// instruction (~2.7 cycles per wave-instruction instead of ~4.4 for the VOP3 form with inline constants, tools/ubench).
+// Used where the two registers stay live across many multiplies (the Poseidon permutation).
 __device__ __forceinline__ void gl_mul_halves_k(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1, u32 k1, u32 km1) {
   u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
   u32 c;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void gl_mul_halves_k(u32 a0, u32 a1, u32 b0, u32 b1, 
   asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
       "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
       "v_sub_co_u32 %0, vcc, %0, %2\n\t"
       "s_nop 1\n\t"

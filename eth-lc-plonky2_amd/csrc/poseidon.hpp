@@ -90,8 +90,8 @@ LCP2_HD void pos_permute_portable(u64 s[12], const u64 *__restrict__ rc) {
 // carry through vcc, cndmask) ~2.7, and v_mad_u64_u32 is a VOP3 op like any other.  So the state is kept as
 // 32-bit halves, products are built from v_mad_u64_u32 and carry chains run through vcc in VOP2 encodings; the
 // compiler's own lowering of a 64x64 multiply + reduction is 27 instructions, this one is 17.  hipcc pads nothing
-// inside an asm string, so the wait states it emits itself for the same pairs on gfx950 (VOP2 writes vcc ->
-// carry-in reader: 2, -> v_cndmask e32: 1, -> e64 reader of vcc: 2) are written out as s_nop here.
+// inside an asm string, so the wait states it emits itself for the same pairs on gfx950 (a VALU write of vcc -> any
+// VALU read of it: 2) are written out as s_nop 1 here; tools/check_hazards.py checks the built library.
 // All values are lazy (any u64 congruent to the element); the final state is canonicalised.
 
 // the select constants of gl_mul_halves_k / pos_fold_h, made opaque to the compiler so that they are materialised once per
@@ -117,7 +117,7 @@ __device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1, con
   const u32 t0 = (u32)t, t1 = (u32)(t >> 32), ah0 = (u32)ah;
   u32 e;
   asm("v_add_co_u32 %1, vcc, %4, %5\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
       "v_add_co_u32 %0, vcc, %3, %2\n\t"
       "s_nop 1\n\t"
