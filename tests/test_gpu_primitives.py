@@ -94,6 +94,34 @@ def test_ntt_large_roundtrip_and_linearity(gpu_ctx):
         assert int(v[0, i]) == pow(7 * pow(w, i, P), 5, P)
 
 
+@pytest.mark.parametrize("lg", [23, 24, 25])
+def test_ntt_three_pass_plans_parity(gpu_ctx, oracle, lg):
+    """Direct evidence for the multi-pass plans the headline proof runs: lg 23-25 are cut 5/5/13 .. 6/6/13 (two strided passes +
+    the contiguous one; 2^25 is the quotient's coset iNTT at n = 2^22).  One column against the oracle's textbook radix-2
+    transform in both directions, with and without the coset shift, plus the definition on a sparse polynomial."""
+    rng = np.random.default_rng(lg)
+    n = 1 << lg
+    x = rand_field(rng, (1, n), canonical=False)
+    xc = x % np.uint64(P)
+    want = xc.copy()
+    oracle.orc_fft(vp(want[0]), n)
+    got = gpu_ctx.ntt_batch(x)
+    assert (got == want).all()
+    assert (gpu_ctx.ntt_batch(want, inverse=True) == xc).all()
+    del got
+    # coset inverse (compute_quotient_polys: values on 7<w> -> coefficients), checked against the oracle's coset_ifft
+    back = xc.copy()
+    oracle.orc_coset_ifft(vp(back[0]), n, 7)
+    assert (gpu_ctx.ntt_batch(x, inverse=True, shift=7) == back).all()
+    assert (gpu_ctx.ntt_batch(back, shift=7) == xc).all()
+    sp = np.zeros((1, n), dtype=np.uint64)
+    sp[0, 3] = 1
+    v = gpu_ctx.ntt_batch(sp, shift=7)
+    w = pow(pow(7, (P - 1) >> 32, P), 1 << (32 - lg), P)
+    for i in (0, 1, 54321, n // 2 + 1, n - 1):
+        assert int(v[0, i]) == pow(7 * pow(w, i, P), 3, P)
+
+
 def test_sha256_tree_golden_roots(gpu_ctx, oracle):
     kat = json.load(open(os.path.join(G, "sha256_kat.json")))
     for n, root in kat["zero_leaf_merkle_roots"].items():

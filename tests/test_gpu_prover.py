@@ -30,7 +30,9 @@ def _first_mismatch(m, params, a, b):
     return f"first mismatch at word {pos} of {total} (in or after section {sec}); {bad.size} words differ"
 
 
-@pytest.mark.parametrize("degree_bits", [5, 6, 8, 10, 12, 13])
+# 14-16: the LDE (2^17 .. 2^19 points) and the quotient iNTT run as two passes (strided + contiguous), the FRI schedule has
+# 3 layers, the scans span several blocks: the multi-pass paths of the headline size inside a whole proof
+@pytest.mark.parametrize("degree_bits", [5, 6, 8, 10, 12, 13, 14, 15, 16])
 def test_proof_equals_oracle(gpu_ctx, oracle, degree_bits):
     import eth_lc_plonky2_amd as m
     params = m.standard_params(degree_bits, 4)
@@ -98,6 +100,57 @@ def test_unsatisfied_witness_gives_rejected_proof(gpu_ctx, oracle):
     assert e.value.check == 3
     data.close()
     oc.close()
+
+
+@pytest.mark.parametrize("round_", range(8))
+def test_parity_soak_seeds(gpu_ctx, oracle, round_):
+    """tools/parity_soak.py folded into the suite: further seeds and sizes, random and small-valued witnesses, and a second
+    proof on the same handle (workspace reuse)."""
+    import eth_lc_plonky2_amd as m
+    db = 5 + (round_ * 3) % 9
+    params = m.standard_params(db, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=7000 + round_, small_values=bool(round_ & 1))
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    want = oc.prove(wires, pis)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    for rep in range(2):
+        got = data.prove(wires, pis)
+        assert _first_mismatch(m, params, got, want) is None, "rep %d: %s" % (rep, _first_mismatch(m, params, got, want))
+    data.close()
+    oc.close()
+
+
+def test_headline_size_proof_verifies(gpu_ctx):
+    """What bench.py times, as a test: build -> prove -> verify at n = 2^22 rows x 135 wires (BASELINE configs[2]); the proof is
+    accepted, a flipped public input and a flipped opening are rejected, and a second proof of the same witness is identical
+    (no state leaks through the 92 GB workspace)."""
+    import torch
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(22, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3, small_values=True)
+    dev = torch.device("cuda", 0)
+    cs_dev = torch.from_numpy(circ.constants_sigmas.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    data = m.CircuitData.build(gpu_ctx, circ, constants_sigmas_ptr=cs_dev.data_ptr(), mem=m.MEM_DEVICE)
+    del cs_dev
+    w_dev = torch.from_numpy(wires.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    del wires
+    proof = data.prove(w_dev.data_ptr(), pis, mem=m.MEM_DEVICE)
+    data.verify(proof, pis)
+    again = data.prove(w_dev.data_ptr(), pis, mem=m.MEM_DEVICE)
+    assert (again == proof).all()
+    wrong = pis.copy()
+    wrong[1] ^= np.uint64(1)
+    with pytest.raises(m.ProofRejected):
+        data.verify(proof, wrong)
+    bad = proof.copy()
+    bad[3 * (4 << params.cap_height) + 7] ^= np.uint64(1)  # an opening
+    with pytest.raises(m.ProofRejected):
+        data.verify(bad, pis)
+    data.close()
+    del w_dev
+    torch.cuda.empty_cache()
 
 
 def test_large_proof_verifies(gpu_ctx):

@@ -50,6 +50,16 @@ DEF_KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1", )
     out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)s ^ (unsigned)(s >> 32);                     \
   }
 DEF_KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+DEF_KERNEL64(k_mad_u64_u32_inl, "v_mad_u64_u32 %0, vcc, %1, 41, %0")          // multiplier as an inline constant (the Poseidon MDS form)
+DEF_KERNEL64(k_mad_u64_u32_sdst, "v_mad_u64_u32 %0, s[10:11], %1, %2, %0")    // carry-out to an SGPR pair instead of vcc
+DEF_KERNEL(k_add_co_u32, "v_add_co_u32 %0, vcc, %0, %1", )
+DEF_KERNEL(k_addc_co_u32, "v_addc_co_u32 %0, vcc, %0, %1, vcc", )
+DEF_KERNEL(k_cndmask_e32, "v_cndmask_b32_e32 %0, %0, %1, vcc", )
+DEF_KERNEL(k_mov_b32, "v_mov_b32 %0, %1", )
+
+DEF_KERNEL(k_dot2_u32_u16, "v_dot2_u32_u16 %0, %0, %1, %2", )
+DEF_KERNEL(k_mul_lo_u32_inl, "v_mul_lo_u32 %0, %0, 41", )
+DEF_KERNEL(k_s_nop1, "s_nop 1", )
 DEF_KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 2, %3")
 DEF_KERNEL64(k_lshlrev_b64, "v_lshlrev_b64 %0, 5, %0")
 DEF_KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %3")
@@ -80,7 +90,8 @@ int main() {
   RUN(k_add_u32); RUN(k_add3_u32); RUN(k_lshl_add_u32); RUN(k_and_or); RUN(k_cndmask); RUN(k_alignbit); RUN(k_perm_b32);
   RUN(k_mul_lo_u32); RUN(k_mul_hi_u32); RUN(k_mul_u32_u24); RUN(k_mul_hi_u32_u24); RUN(k_mad_u32_u24); RUN(k_mad_i32_i24);
   RUN(k_dot4_u32_u8); RUN(k_pk_mul_lo_u16); RUN(k_pk_mad_u16); RUN(k_pk_add_u16);
-  RUN(k_mad_u64_u32); RUN(k_lshl_add_u64); RUN(k_lshlrev_b64);
+  RUN(k_mad_u64_u32); RUN(k_mad_u64_u32_inl); RUN(k_mad_u64_u32_sdst); RUN(k_lshl_add_u64); RUN(k_lshlrev_b64);
+  RUN(k_add_co_u32); RUN(k_addc_co_u32); RUN(k_cndmask_e32); RUN(k_mov_b32); RUN(k_dot2_u32_u16); RUN(k_mul_lo_u32_inl); RUN(k_s_nop1);
   RUN(k_fma_f32); RUN(k_pk_fma_f32); RUN(k_mul_f64); RUN(k_fma_f64);
   return 0;
 }
