@@ -152,8 +152,8 @@ def main():
     torch.cuda.synchronize()
     data = m.CircuitData.build(ctx, circ, constants_sigmas_ptr=cs_dev.data_ptr(), mem=m.MEM_DEVICE)
     del cs_dev
-    # each rank proves its own witness: an unconstrained wire column carries the (rank, update) tag
-    wires[134] = np.uint64(rank + 1)
+    # each rank proves its own witness: the free cells of the padding row carry the (rank, update) tag
+    m.circuit.tag_witness(wires, rank + 1)
     w_dev = torch.from_numpy(wires.view(np.int64)).to(dev)
     torch.cuda.synchronize()
     del wires  # 4.5 GB of host memory per rank; the witness lives in HBM from here on

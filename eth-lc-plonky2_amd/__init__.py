@@ -10,5 +10,6 @@ from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Pa
 from .build import build_native  # noqa: F401
 from . import binding  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402
+from . import poseidon_py  # noqa: F401,E402
 from . import batch  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402

@@ -116,7 +116,7 @@ def load_library():
         "lcp2_circuit_destroy": (None, [c.c_void_p]),
         "lcp2_circuit_digest": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_proof_words": (c.c_size_t, [c.POINTER(Params)]),
-        "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p]),
+        "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]),
         "lcp2_commit_wires": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]),
         "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
@@ -130,7 +130,7 @@ def load_library():
         "lcp2_quotient_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient_buffer": (c.c_int, [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]),
         "lcp2_quotient_commit": (c.c_int, [c.c_void_p, c.c_void_p]),
-        "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.POINTER(c.c_int)]),
+        "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_int)]),
         "lcp2_last_challenges": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
         "lcp2_prof_reset": (c.c_int, [c.c_void_p]),
@@ -424,9 +424,10 @@ class CircuitData:
         cp = _np_u64(cap)
         self._check(self.lib.lcp2_circuit_set_constants_cap(self.handle, _ptr(cp)))
 
-    def quotient_values(self, alphas, public_inputs):
-        a, pis = _np_u64(alphas), _np_u64(public_inputs)
-        self._check(self.lib.lcp2_quotient_values(self.handle, _ptr(a), _ptr(pis)))
+    def quotient_values(self, alphas, public_inputs_hash):
+        a, h = _np_u64(alphas), _np_u64(public_inputs_hash)
+        assert h.size == 4
+        self._check(self.lib.lcp2_quotient_values(self.handle, _ptr(a), _ptr(h)))
 
     def quotient_buffer(self):
         """(device pointer, uint64 words) of the quotient values [num_challenges][8n]: the one bulk exchange of a sharded proof"""
@@ -464,14 +465,16 @@ class CircuitData:
 
     def prove(self, wires, public_inputs, mem=MEM_HOST):
         """data.prove(pw): wires = full witness [num_wires][n] (numpy, or a device pointer with mem=MEM_DEVICE)"""
-        pis = _np_u64(public_inputs)
+        pis = _np_u64(public_inputs).ravel()
         proof = np.zeros(self.proof_words, dtype=np.uint64)
         if mem == MEM_HOST:
             w = _np_u64(wires)
+            if w.shape != (self.circ.params.num_wires, 1 << self.circ.params.degree_bits):
+                raise Lcp2Error(-1, "witness must be [num_wires][n]")
             wp = _ptr(w)
         else:
             wp = ctypes.c_void_p(wires)
-        self._check(self.lib.lcp2_prove(self.handle, wp, mem, _ptr(pis), _ptr(proof)))
+        self._check(self.lib.lcp2_prove(self.handle, wp, mem, _ptr(pis), pis.size, _ptr(proof), proof.size))
         return proof
 
     # ---- the seams of data.prove() one by one (the caller runs the Fiat-Shamir transcript)
@@ -493,9 +496,11 @@ class CircuitData:
         self._check(self.lib.lcp2_perm_zs(self.handle, _ptr(b), _ptr(g), _ptr(cap)))
         return cap
 
-    def quotient(self, alphas, public_inputs):
-        cap, a, pis = self._cap(), _np_u64(alphas), _np_u64(public_inputs)
-        self._check(self.lib.lcp2_quotient(self.handle, _ptr(a), _ptr(pis), _ptr(cap)))
+    def quotient(self, alphas, public_inputs_hash):
+        """compute_quotient_polys + commitment; takes public_inputs_hash (4 elements) as plonky2's function does"""
+        cap, a, h = self._cap(), _np_u64(alphas), _np_u64(public_inputs_hash)
+        assert h.size == 4
+        self._check(self.lib.lcp2_quotient(self.handle, _ptr(a), _ptr(h), _ptr(cap)))
         return cap
 
     def fri_open(self, zeta, challenger_state, proof):
@@ -507,8 +512,9 @@ class CircuitData:
     def verify(self, proof, public_inputs):
         """data.verify(proof): raises ProofRejected like the reference's unwrap()"""
         failed = ctypes.c_int(0)
-        pr, pis = _np_u64(proof), _np_u64(public_inputs)
-        rc = self.lib.lcp2_verify(self.handle, _ptr(pr), _ptr(pis), ctypes.byref(failed))
+        pr, pis = _np_u64(proof).ravel(), _np_u64(public_inputs).ravel()
+        # the lengths travel with the buffers: the library refuses a proof that is not exactly lcp2_proof_words() long
+        rc = self.lib.lcp2_verify(self.handle, _ptr(pr), pr.size, _ptr(pis), pis.size, ctypes.byref(failed))
         if rc == -7:
             raise ProofRejected(failed.value)
         self._check(rc)

@@ -2,30 +2,56 @@
 
 This is the data a `CircuitBuilder::build()` hands to the prover (plonky2 0.1.4
 plonk/circuit_builder.rs, gates/selectors.rs; reference call site
-eth-lc-plonky2/src/main.rs:227).  The real gate set of plonky2 / plonky2_crypto is not
-visible from the reference (un-vendored crates), so gates are described by a small
-constraint bytecode that the K6 kernel (and the verifier) interpret:
+eth-lc-plonky2/src/main.rs:227).  plonky2's gate objects cannot cross a C ABI, so every gate
+type is described by a small constraint bytecode that the K6 kernel (and the verifier) interpret
+(include/lcp2.h has the instruction format):
 
     word0 = op | dst << 8 | kind_a << 16 | kind_b << 20      word1 = idx_a | idx_b << 16
-    op:   0 ADD  1 SUB  2 MUL  3 EMIT(a)        kind: 0 REG 1 WIRE 2 CONST 3 IMM 4 PI
-    EMIT folds a constraint into the running  acc <- acc * alpha + a , so a gate lists its
-    constraints from the last to the first.
+    op:   0 ADD  1 SUB  2 MUL  3 EMIT(a)  4 XOR  5 DBLADD  6 EMITBOOL  7 MULADD  8 SBOX (a^7)  9 PMDS (Poseidon MDS layer)
+    kind: 0 REG 1 WIRE 2 CONST 3 IMM 4 PI (public_inputs_hash[idx])
+
+The gate library below restates `eval_unfiltered` of the plonky2 gates a circuit built with
+`standard_recursion_config` and no recursion contains: NoopGate, ConstantGate, PublicInputGate,
+BaseSumGate<2>, ArithmeticGate and PoseidonGate ([RECALL] of the published source: the crate is not in the
+reference repository, see DESIGN.md "Oracle").
 """
 import ctypes
 
 import numpy as np
 
 from . import gl_np as gl
+from . import poseidon_py as pos
 
-OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_XOR, OP_DBLADD, OP_EMITBOOL, OP_MULADD = 0, 1, 2, 3, 4, 5, 6, 7
+OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_XOR, OP_DBLADD, OP_EMITBOOL, OP_MULADD, OP_SBOX, OP_PMDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 K_REG, K_WIRE, K_CONST, K_IMM, K_PI = 0, 1, 2, 3, 4
 UNUSED_SELECTOR = 0xFFFFFFFF
 MAX_REGS = 64
+GATE_EMIT_FORWARD = 1
+GATE_NATIVE_POSEIDON = 0x100  # the claim "this program is plonky2's PoseidonGate": checked by lcp2_circuit_create against its native evaluator
 
 
 class Gate(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ("selector_index", "selector_value", "group_start", "group_end",
-                                               "code_offset", "code_len", "num_constraints")]
+                                               "code_offset", "code_len", "num_constraints", "flags")]
+
+
+class ImmTable:
+    """immediates of a gate set: single values are shared, blocks (the 12 constants of a PMDS) are contiguous"""
+
+    def __init__(self):
+        self.values, self.index = [], {}
+
+    def get(self, value):
+        value = int(value) % gl.P
+        if value not in self.index:
+            self.index[value] = len(self.values)
+            self.values.append(value)
+        return self.index[value]
+
+    def block(self, values):
+        base = len(self.values)
+        self.values += [int(v) % gl.P for v in values]
+        return base
 
 
 def R(i):
@@ -53,17 +79,21 @@ class GateAsm:
         self.free = list(range(MAX_REGS - 1, -1, -1))
         self.max_reg = 0
         self.num_constraints = 0
+        self.flags = 0
 
     def imm(self, value):
-        value = int(value) % gl.P
-        if value not in self.imm_table:
-            self.imm_table[value] = len(self.imm_table)
-        return (K_IMM, self.imm_table[value])
+        return (K_IMM, self.imm_table.get(value))
 
     def _alloc(self):
         r = self.free.pop()
         self.max_reg = max(self.max_reg, r + 1)
         return r
+
+    def reserve(self, first, count):
+        """take registers [first, first + count) out of the free list (a PMDS window)"""
+        for r in range(first, first + count):
+            self.free.remove(r)
+        self.max_reg = max(self.max_reg, first + count)
 
     def release(self, *ops):
         for o in ops:
@@ -72,30 +102,40 @@ class GateAsm:
 
     def _op(self, op, a, b, dst=None):
         d = self._alloc() if dst is None else dst
+        self.max_reg = max(self.max_reg, d + 1)
         self.words += [op | d << 8 | a[0] << 16 | b[0] << 20, a[1] | b[1] << 16]
         return (K_REG, d)
 
-    def add(self, a, b):
-        return self._op(OP_ADD, a, b)
+    def add(self, a, b, dst=None):
+        return self._op(OP_ADD, a, b, dst)
 
-    def sub(self, a, b):
-        return self._op(OP_SUB, a, b)
+    def sub(self, a, b, dst=None):
+        return self._op(OP_SUB, a, b, dst)
 
-    def mul(self, a, b):
-        return self._op(OP_MUL, a, b)
+    def mul(self, a, b, dst=None):
+        return self._op(OP_MUL, a, b, dst)
 
     def xor(self, a, b):
         """a + b - 2ab (a ^ b on bits)"""
         return self._op(OP_XOR, a, b)
 
-    def dbladd(self, a, b):
+    def dbladd(self, a, b, dst=None):
         """2a + b (one Horner step of a bit recomposition)"""
-        return self._op(OP_DBLADD, a, b)
+        return self._op(OP_DBLADD, a, b, dst)
 
     def muladd(self, acc, a, b):
         """acc <- acc + a * b; acc must be a register operand"""
         assert acc[0] == K_REG
         return self._op(OP_MULADD, a, b, dst=acc[1])
+
+    def sbox(self, a, dst):
+        """reg[dst] <- a^7"""
+        return self._op(OP_SBOX, a, (K_REG, 0), dst)
+
+    def pmds(self, dst, src, constants):
+        """reg[dst .. dst+12) <- MDS * reg[src .. src+12) + constants (12 immediates)"""
+        base = self.imm_table.block(constants)
+        self.words += [OP_PMDS | dst << 8 | K_REG << 16 | K_IMM << 20, src | base << 16]
 
     def emit(self, a):
         self.words += [OP_EMIT | a[0] << 16, a[1]]
@@ -107,24 +147,24 @@ class GateAsm:
         self.num_constraints += 1
 
 
-# ---------------------------------------------------------------- gate library (own layout)
+# ---------------------------------------------------------------- gate library: plonky2's gates as constraint programs
 def gate_noop(asm):
     """NoopGate: no constraints (padding rows)."""
 
 
-def gate_public_input(npi):
-    def build(asm):
-        for i in reversed(range(npi)):  # wire_i - public_input_i
-            t = asm.sub(W(i), PI(i))
-            asm.emit(t)
-            asm.release(t)
-    return build
+def gate_public_input(asm):
+    """PublicInputGate (gates/public_input.rs): wires 0..4 = public_inputs_hash.  The public inputs themselves are hashed
+    in-circuit by PoseidonGate rows whose output is copy-constrained to these wires (circuit_builder.rs::build)."""
+    for i in reversed(range(4)):
+        t = asm.sub(W(i), PI(i))
+        asm.emit(t)
+        asm.release(t)
 
 
 def gate_constant(asm):
-    """ConstantGate: wire_i = const_i for the two gate constants."""
+    """ConstantGate { num_consts: 2 } (gates/constant.rs): local_constants[i] - local_wires[i]."""
     for i in (1, 0):
-        t = asm.sub(W(i), C(i))
+        t = asm.sub(C(i), W(i))
         asm.emit(t)
         asm.release(t)
 
@@ -133,32 +173,96 @@ ARITH_OPS = 20
 
 
 def gate_arithmetic(asm):
-    """ArithmeticGate (base): c0 * x * y + c1 * z - out over 20 groups of 4 routed wires."""
+    """ArithmeticGate { num_ops: 20 } (gates/arithmetic_base.rs): output - (c0 * multiplicand_0 * multiplicand_1 + c1 * addend)
+    over wires 4i .. 4i+3 = multiplicand_0, multiplicand_1, addend, output."""
     for k in reversed(range(ARITH_OPS)):
         xy = asm.mul(W(4 * k), W(4 * k + 1))
         t = asm.mul(xy, C(0))
         u = asm.mul(W(4 * k + 2), C(1))
         s = asm.add(t, u)
-        d = asm.sub(s, W(4 * k + 3))
+        d = asm.sub(W(4 * k + 3), s)
         asm.emit(d)
         asm.release(xy, t, u, s, d)
 
 
-SBOX_LANES = 12
+BASE_SUM_LIMBS = 63
 
 
-def gate_sbox7(asm):
-    """Degree-7 gate: wire[80+2i+1] = wire[80+2i]^7 for 12 lanes of unrouted wires (the x^7 S-box shape of the
-    Poseidon gate; exercises the maximum constraint degree the quotient domain allows)."""
-    for i in reversed(range(SBOX_LANES)):
-        x = W(80 + 2 * i)
-        x2 = asm.mul(x, x)
-        x4 = asm.mul(x2, x2)
-        x3 = asm.mul(x2, x)
-        x7 = asm.mul(x3, x4)
-        d = asm.sub(x7, W(80 + 2 * i + 1))
-        asm.emit(d)
-        asm.release(x2, x4, x3, x7, d)
+def gate_base_sum(num_limbs=BASE_SUM_LIMBS):
+    """BaseSumGate<2> { num_limbs } (gates/base_sum.rs): wire 0 = sum, wires 1 .. num_limbs = little-endian bits.
+    constraints: [reduce_with_powers(limbs, 2) - sum] ++ [limb * (limb - 1) for every limb]"""
+    def build(asm):
+        for i in reversed(range(num_limbs)):
+            asm.emit_bool(W(1 + i))
+        acc = asm.dbladd(W(num_limbs), W(num_limbs - 1))
+        for i in reversed(range(num_limbs - 2)):
+            asm.dbladd(acc, W(1 + i), dst=acc[1])
+        asm.sub(acc, W(0), dst=acc[1])
+        asm.emit(acc)
+        asm.release(acc)
+    return build
+
+
+def gate_poseidon(asm):
+    """PoseidonGate (gates/poseidon.rs): one permutation per row, 135 wires, 123 constraints of degree 7, in the order of
+    eval_unfiltered: swap booleanity, the 4 delta equations, then for every S-box that has a wire (full rounds 1-3, the 22
+    partial rounds, full rounds 4-7) `state - sbox_in`, last the 12 outputs.  The constraints fall out of one forward pass
+    over the rounds, so the program emits them first to last (GATE_EMIT_FORWARD).  The partial rounds are written in the
+    naive form (add 12 constants, S-box on lane 0, MDS): plonky2's fast-partial-round form computes the same lane-0 values
+    and is the same polynomial in the wires."""
+    rc = pos.round_constants()
+    asm.flags |= GATE_EMIT_FORWARD | GATE_NATIVE_POSEIDON
+    asm.reserve(0, 12)  # the state window
+    S = [R(i) for i in range(12)]
+    asm.emit_bool(W(pos.W_SWAP))
+    t = (K_REG, asm._alloc())
+    for i in range(4):  # swap * (input[i+4] - input[i]) - delta_i
+        asm.sub(W(pos.W_INPUT + i + 4), W(pos.W_INPUT + i), dst=t[1])
+        asm.mul(t, W(pos.W_SWAP), dst=t[1])
+        asm.sub(t, W(pos.W_DELTA + i), dst=t[1])
+        asm.emit(t)
+    # state after the swap, with the first round's constants added
+    for i in range(4):
+        asm.add(W(pos.W_INPUT + i), W(pos.W_DELTA + i), dst=i)
+        asm.add(S[i], asm.imm(rc[i]), dst=i)
+        asm.sub(W(pos.W_INPUT + i + 4), W(pos.W_DELTA + i), dst=i + 4)
+        asm.add(S[i + 4], asm.imm(rc[i + 4]), dst=i + 4)
+    for i in range(8, 12):
+        asm.add(W(pos.W_INPUT + i), asm.imm(rc[i]), dst=i)
+    rnd = 0
+
+    def next_constants():
+        return rc[12 * (rnd + 1):12 * (rnd + 2)] if rnd + 1 < pos.N_ROUNDS else [0] * 12
+
+    for r in range(pos.N_FULL_HALF):
+        for i in range(12):
+            src = S[i]
+            if r:
+                src = W(pos.wire_full_sbox_0(r, i))
+                asm.sub(S[i], src, dst=t[1])
+                asm.emit(t)
+            asm.sbox(src, dst=i)
+        asm.pmds(0, 0, next_constants())
+        rnd += 1
+    for r in range(pos.N_PARTIAL):
+        src = W(pos.wire_partial_sbox(r))
+        asm.sub(S[0], src, dst=t[1])
+        asm.emit(t)
+        asm.sbox(src, dst=0)
+        asm.pmds(0, 0, next_constants())
+        rnd += 1
+    for r in range(pos.N_FULL_HALF):
+        for i in range(12):
+            src = W(pos.wire_full_sbox_1(r, i))
+            asm.sub(S[i], src, dst=t[1])
+            asm.emit(t)
+            asm.sbox(src, dst=i)
+        asm.pmds(0, 0, next_constants())
+        rnd += 1
+    for i in range(12):
+        asm.sub(S[i], W(pos.W_OUTPUT + i), dst=t[1])
+        asm.emit(t)
+    asm.release(t)
 
 
 class GateSet:
@@ -168,7 +272,7 @@ class GateSet:
         # gates: list of (name, degree, build_fn), already sorted by (degree, name) as plonky2 sorts its gate set
         self.names = [g[0] for g in gates]
         self.degrees = [g[1] for g in gates]
-        self.imm_table = {}
+        self.imm_table = ImmTable()
         code, self.gates = [], []
         groups = []
         n = len(gates)
@@ -190,16 +294,13 @@ class GateSet:
             asm = GateAsm(self.imm_table)
             fn(asm)
             sel = next(i for i, (a, b) in enumerate(groups) if a <= gi < b)
-            g = Gate(sel, gi, groups[sel][0], groups[sel][1], len(code) // 2, len(asm.words) // 2, asm.num_constraints)
+            g = Gate(sel, gi, groups[sel][0], groups[sel][1], len(code) // 2, len(asm.words) // 2, asm.num_constraints, asm.flags)
             code += asm.words
             self.gates.append(g)
             self.max_regs = max(self.max_regs, asm.max_reg)
         self.code = np.array(code if code else [0, 0], dtype=np.uint32)
         self.code_len = len(code)
-        imm = [0] * max(len(self.imm_table), 1)
-        for v, i in self.imm_table.items():
-            imm[i] = v
-        self.imm = np.array(imm, dtype=np.uint64)
+        self.imm = np.array(self.imm_table.values if self.imm_table.values else [0], dtype=np.uint64)
 
     def index(self, name):
         return self.names.index(name)
@@ -241,40 +342,53 @@ def sigma_values(sig_row, sig_col, k_is, degree_bits):
     return out
 
 
-def standard_gateset(npi):
+def standard_gateset():
+    """The gate set of a plonky2 circuit without recursion under standard_recursion_config, sorted as plonky2 sorts it
+    (degree, then id): two selector groups (gates of degree <= 3, PoseidonGate), so 4 constant columns."""
     return GateSet([
-        ("noop", 0, gate_noop),
-        ("constant", 1, gate_constant),
-        ("public_input", 1, gate_public_input(npi)),
-        ("arithmetic", 3, gate_arithmetic),
-        ("sbox7", 7, gate_sbox7),
+        ("NoopGate", 0, gate_noop),
+        ("ConstantGate", 1, gate_constant),
+        ("PublicInputGate", 1, gate_public_input),
+        ("BaseSumGate", 2, gate_base_sum(BASE_SUM_LIMBS)),
+        ("ArithmeticGate", 3, gate_arithmetic),
+        ("PoseidonGate", 7, gate_poseidon),
     ])
 
 
 def synthetic_circuit(params, seed, npi=4, small_values=False):
-    """A satisfiable circuit of 2^degree_bits rows over the standard gate set with real copy constraints:
-    arithmetic rows are paired (the second row's x inputs are the first row's outputs), the first arithmetic
-    row reads the public inputs, and one constant is fanned out to many rows (a long permutation cycle).
+    """A satisfiable circuit of 2^degree_bits rows over plonky2's own gate set with real copy constraints, laid out the way
+    circuit_builder.rs::build lays a circuit out:
+      row 0        PublicInputGate: wires 0..4 carry public_inputs_hash
+      rows 1..     ConstantGate rows (one holds the constant 0 that pads the sponge and drives `swap`)
+      next rows    PoseidonGate rows hashing the public inputs (hash_n_to_hash_no_pad: overwrite-mode sponge, rate 8), the
+                   digest copy-constrained to row 0, the inputs copy-constrained to the cells that hold the public inputs
+      every 16th   BaseSumGate<2> row (63 limbs) decomposing a random 63-bit value
+      the rest     ArithmeticGate rows in pairs (the second row's multiplicands are the first row's outputs), the first one
+                   reads the public inputs, one constant is fanned out to every 8th pair (a long permutation cycle)
+      last rows    NoopGate padding
     Returns (Circuit, wires [num_wires][n], public_inputs)."""
     rng = np.random.default_rng(seed)
     n = 1 << params.degree_bits
     Wn, NR = params.num_wires, params.num_routed_wires
-    gs = standard_gateset(npi)
-    assert params.num_constants == gs.num_selectors + 2
+    gs = standard_gateset()
+    assert params.num_constants == gs.num_selectors + 2 and Wn >= pos.NUM_WIRES and NR >= 80
     G = {name: gs.index(name) for name in gs.names}
     rows = np.arange(n)
-    gate_of_row = np.full(n, G["arithmetic"], dtype=np.int64)
-    gate_of_row[0] = G["public_input"]
+    nperm = -(-npi // 8) if npi else 0       # PoseidonGate rows of the public-input hash
     nconst = min(3, max(n - 2, 1))
-    gate_of_row[1:1 + nconst] = G["constant"]
-    gate_of_row[rows % 16 == 5] = G["sbox7"] if n >= 32 else G["arithmetic"]
-    gate_of_row[0] = G["public_input"]
-    gate_of_row[1:1 + nconst] = G["constant"]
+    assert n >= 1 + nconst + nperm + 4, "circuit too small for the public-input hash"
+    gate_of_row = np.full(n, G["ArithmeticGate"], dtype=np.int64)
+    gate_of_row[rows % 16 == 5] = G["BaseSumGate"] if n >= 32 else G["ArithmeticGate"]
+    gate_of_row[0] = G["PublicInputGate"]
+    crow = np.arange(1, 1 + nconst)
+    gate_of_row[crow] = G["ConstantGate"]
+    prow = np.arange(1 + nconst, 1 + nconst + nperm)
+    gate_of_row[prow] = G["PoseidonGate"]
     npad = min(4, n // 4)
-    gate_of_row[n - npad:] = G["noop"]
-    arith = np.nonzero(gate_of_row == G["arithmetic"])[0]
+    gate_of_row[n - npad:] = G["NoopGate"]
+    arith = np.nonzero(gate_of_row == G["ArithmeticGate"])[0]
     if arith.size % 2:
-        gate_of_row[arith[-1]] = G["noop"]
+        gate_of_row[arith[-1]] = G["NoopGate"]
         arith = arith[:-1]
     hi = 256 if small_values else gl.P
     wires = rng.integers(0, hi, size=(Wn, n), dtype=np.uint64)
@@ -288,24 +402,27 @@ def synthetic_circuit(params, seed, npi=4, small_values=False):
         sig_row[ca, ra], sig_col[ca, ra] = rb, cb
         sig_row[cb, rb], sig_col[cb, rb] = ra, ca
 
-    # public inputs
-    wires[:npi, 0] = pis
-    # constants
-    crow = np.arange(1, 1 + nconst)
+    def cycle(cells):  # one copy-constraint cycle through a list of (row, col) cells
+        r = np.array([c[0] for c in cells])
+        c = np.array([c[1] for c in cells])
+        sig_row[c, r] = np.roll(r, -1)
+        sig_col[c, r] = np.roll(c, -1)
+
+    # constants: wire_i = const_i on the ConstantGate rows; the last one provides the constant zero
+    zero_row = int(crow[-1])
+    c0[zero_row] = 0
     wires[0, crow], wires[1, crow] = c0[crow], c1[crow]
+    pi_cells = [[] for _ in range(npi)]   # every cell that must equal public input k
     if arith.size:
         first, second = arith[0::2], arith[1::2]
-        # the first arithmetic row reads the public inputs on its y inputs
+        # the first arithmetic row reads the public inputs on its multiplicand_1 inputs
         for k in range(min(npi, ARITH_OPS)):
             wires[4 * k + 1, first[0]] = pis[k]
-            link2(np.array([first[0]]), 4 * k + 1, np.array([0]), k)
-        # fan one constant out to the z input of op 0 of every 8th first-row: one long cycle
+            pi_cells[k].append((int(first[0]), 4 * k + 1))
+        # fan one constant out to the addend of op 0 of every 8th first-row: one long cycle
         fan = first[::8]
         wires[2, fan] = c0[1]
-        cyc_r = np.concatenate([[1], fan])
-        cyc_c = np.concatenate([[0], np.full(fan.size, 2)])
-        sig_row[cyc_c, cyc_r] = np.roll(cyc_r, -1)
-        sig_col[cyc_c, cyc_r] = np.roll(cyc_c, -1)
+        cycle([(1, 0)] + [(int(r), 2) for r in fan])
         for k in range(ARITH_OPS):
             x, y, z = wires[4 * k, first], wires[4 * k + 1, first], wires[4 * k + 2, first]
             out = gl.add(gl.mul(gl.mul(x, y), c0[first]), gl.mul(z, c1[first]))
@@ -314,14 +431,53 @@ def synthetic_circuit(params, seed, npi=4, small_values=False):
             link2(second, 4 * k, first, 4 * k + 3)
             y2, z2 = wires[4 * k + 1, second], wires[4 * k + 2, second]
             wires[4 * k + 3, second] = gl.add(gl.mul(gl.mul(out, y2), c0[second]), gl.mul(z2, c1[second]))
-    sb = np.nonzero(gate_of_row == G["sbox7"])[0]
-    for i in range(SBOX_LANES):
-        x = wires[80 + 2 * i, sb]
-        x2 = gl.mul(x, x)
-        x4 = gl.mul(x2, x2)
-        wires[80 + 2 * i + 1, sb] = gl.mul(gl.mul(x2, x), x4)
+    # BaseSumGate<2>: wire 0 = sum, wires 1..63 = its bits
+    bs = np.nonzero(gate_of_row == G["BaseSumGate"])[0]
+    if bs.size:
+        val = rng.integers(0, 256 if small_values else 1 << 63, size=bs.size, dtype=np.uint64)
+        wires[0, bs] = val
+        for i in range(BASE_SUM_LIMBS):
+            wires[1 + i, bs] = (val >> np.uint64(i)) & np.uint64(1)
+    # the public-input hash, in-circuit: one PoseidonGate row per chunk of 8 inputs
+    zero_cells = [(zero_row, 0)]
+    state = [0] * 12
+    prev_row = None
+    for j, r in enumerate(prow):
+        r = int(r)
+        chunk = [int(v) for v in pis[8 * j:8 * j + 8]]
+        state[:len(chunk)] = chunk
+        row = pos.gate_row(state, 0)
+        wires[:pos.NUM_WIRES, r] = np.array(row, dtype=np.uint64)
+        for i in range(12):
+            if i < len(chunk):
+                pi_cells[8 * j + i].append((r, pos.W_INPUT + i))
+            elif prev_row is None:
+                zero_cells.append((r, pos.W_INPUT + i))          # the sponge starts from the zero state
+            else:
+                link2(np.array([r]), pos.W_INPUT + i, np.array([prev_row]), pos.W_OUTPUT + i)  # lanes the chunk does not overwrite
+        zero_cells.append((r, pos.W_SWAP))
+        state = row[pos.W_OUTPUT:pos.W_OUTPUT + 12]
+        prev_row = r
+    pi_hash = pos.hash_no_pad(pis)
+    wires[:4, 0] = np.array(pi_hash, dtype=np.uint64)
+    if prev_row is not None:
+        assert list(state[:4]) == pi_hash
+        for i in range(4):
+            link2(np.array([0]), i, np.array([prev_row]), pos.W_OUTPUT + i)
+    if len(zero_cells) > 1:
+        cycle(zero_cells)
+    for cells in pi_cells:
+        if len(cells) > 1:
+            cycle(cells)
     k_is = gl.powers(7, NR)
     sig = sigma_values(sig_row, sig_col, k_is, params.degree_bits)
     consts = np.concatenate([gs.selector_columns(gate_of_row), c0[None, :], c1[None, :]])
     cs = np.concatenate([consts, sig])
     return Circuit(params, gs, cs, k_is, npi), wires, pis
+
+
+def tag_witness(wires, tag):
+    """A different witness of the same synthetic circuit: the last row is NoopGate padding, so its cells are free (no gate
+    constraint, identity permutation).  Used to give every rank / update of a batch a proof of its own."""
+    wires[100:, -1] = np.uint64(int(tag) % gl.P)
+    return wires

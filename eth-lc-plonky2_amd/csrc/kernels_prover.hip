@@ -175,6 +175,13 @@ void launch_perm_finalize(hipStream_t s, const PermArgs &a) {
   hipLaunchKernelGGL(k_perm_finalize, dim3((unsigned)((a.n + 255) / 256), a.num_challenges), dim3(256), 0, s, a);
 }
 
+// Read-only tables reached through an argument struct carry no `__restrict__`, so hipcc cannot prove a uniform load from them
+// invariant and emits a vector load + v_readfirstlane (a full memory round trip on the critical path of every interpreter
+// instruction).  Viewed through the constant address space the same load is an s_load from the scalar cache.  Only for data
+// that no kernel writes while this one runs (code, gate table, immediates, challenges: all uploaded before the launch).
+template <class T> using const_as = const T __attribute__((address_space(4))) *;
+template <class T> __device__ __forceinline__ const_as<T> konst(const T *p) { return (const_as<T>)(unsigned long long)p; }
+
 // ------------------------------------------------------------------ K6: quotient polynomial values on the LDE coset
 // Gate-program interpreter: registers live in LDS (reg r of thread t at lds[r * T + t]: conflict free), decode is
 // wave-uniform (scalar unit), operands come from the wires / constants LDE columns at this thread's point.
@@ -183,9 +190,274 @@ __device__ __forceinline__ u64 q_operand(const QuotientArgs &a, u32 kind, u32 id
     case 0: return lds[idx * T + tid];
     case 1: return a.wires[(u64)idx * a.stride + i];
     case 2: return a.consts[(u64)(a.num_selectors + idx) * a.stride + i];
-    case 3: return a.imm[idx];
-    default: return a.pis[idx];
+    case 3: return konst(a.imm)[idx];
+    case 4: return konst(a.pis)[idx];
+    default: return lds[(a.num_regs + idx) * T + tid];  // QKIND_STAGE
   }
+}
+
+// LDG: `cnt` column values of this thread's point into the staging slots.  All QUOTIENT_STAGE loads are issued back to back
+// (lanes past `cnt` repeat entry 0) before the first one is used: one HBM round trip for the whole group.
+__device__ __forceinline__ void q_stage(const QuotientArgs &a, u32 cnt, const_as<u32> lst, u64 *lds, u32 T, u32 tid, u64 i) {
+  u64 v[QUOTIENT_STAGE];
+#pragma unroll
+  for (u32 j = 0; j < QUOTIENT_STAGE; j++) {
+    const u32 e = lst[j < cnt ? j : 0];
+    const u64 *col = e < a.num_wires ? a.wires + (u64)e * a.stride : a.consts + (u64)(e - a.num_wires) * a.stride;
+    v[j] = col[i];
+  }
+#pragma unroll
+  for (u32 j = 0; j < QUOTIENT_STAGE; j++)
+    if (j < cnt) lds[(a.num_regs + j) * T + tid] = v[j];
+}
+
+// Host: the staged form of the programs.  Instructions are scanned in order; when one needs a WIRE / CONST operand that is not
+// in the current window, a new window opens: the distinct column operands of the instructions ahead are collected (in order of
+// first use) until QUOTIENT_STAGE of them are found, one LDG fetches them, and operands are rewritten to their slots.
+void stage_gate_programs(const std::vector<uint32_t> &code, std::vector<GateDev> &gates, u32 num_wires, u32 num_selectors,
+                         std::vector<uint32_t> &out, std::vector<uint32_t> &lists) {
+  out.clear(); lists.clear();
+  auto column_of = [&](u32 kind, u32 idx) { return kind == 1 ? idx : num_wires + num_selectors + idx; };
+  auto nsrc_of = [](u32 op) { return (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL || op == LCP2_OP_SBOX) ? 1u : op == LCP2_OP_PMDS ? 0u : 2u; };
+  for (GateDev &G : gates) {
+    const u32 first = G.code_offset, last = G.code_offset + G.code_len, new_first = (u32)out.size() / 2;
+    std::vector<u32> window;  // columns staged by the last LDG
+    for (u32 pc = first; pc < last; pc++) {
+      u32 w0 = code[2 * pc], w1 = code[2 * pc + 1];
+      const u32 op = w0 & 0xF;
+      u32 kk[2] = {(w0 >> 16) & 0xF, (w0 >> 20) & 0xF}, ii[2] = {w1 & 0xFFFF, w1 >> 16};
+      const u32 nsrc = nsrc_of(op);
+      auto slot_of = [&](u32 col) { for (u32 s = 0; s < window.size(); s++) if (window[s] == col) return (int)s; return -1; };
+      bool missing = false;
+      for (u32 k = 0; k < nsrc; k++)
+        if ((kk[k] == 1 || kk[k] == 2) && slot_of(column_of(kk[k], ii[k])) < 0) missing = true;
+      if (missing) {  // open a new window from here
+        window.clear();
+        for (u32 q = pc; q < last && window.size() < QUOTIENT_STAGE; q++) {
+          const u32 v0 = code[2 * q], v1 = code[2 * q + 1], o = v0 & 0xF;
+          const u32 k2[2] = {(v0 >> 16) & 0xF, (v0 >> 20) & 0xF}, i2[2] = {v1 & 0xFFFF, v1 >> 16};
+          std::vector<u32> need;
+          for (u32 k = 0; k < nsrc_of(o); k++)
+            if (k2[k] == 1 || k2[k] == 2) {
+              const u32 col = column_of(k2[k], i2[k]);
+              bool have = false;
+              for (u32 c : window) have = have || c == col;
+              for (u32 c : need) have = have || c == col;
+              if (!have) need.push_back(col);
+            }
+          if (window.size() + need.size() > QUOTIENT_STAGE) break;  // an instruction's operands never straddle two windows
+          window.insert(window.end(), need.begin(), need.end());
+        }
+        out.push_back(QOP_LDG | (u32)window.size() << 8);
+        out.push_back((u32)lists.size());
+        lists.insert(lists.end(), window.begin(), window.end());
+      }
+      for (u32 k = 0; k < nsrc; k++)
+        if (kk[k] == 1 || kk[k] == 2) { ii[k] = (u32)slot_of(column_of(kk[k], ii[k])); kk[k] = QKIND_STAGE; }
+      if (op != LCP2_OP_PMDS) {
+        w0 = (w0 & 0xFFFF) | kk[0] << 16 | kk[1] << 20;
+        w1 = (nsrc >= 1 ? ii[0] : (w1 & 0xFFFF)) | (nsrc >= 2 ? ii[1] : (w1 >> 16)) << 16;
+      }
+      out.push_back(w0); out.push_back(w1);
+    }
+    G.code_offset = new_first;
+    G.code_len = (u32)out.size() / 2 - new_first;
+  }
+  lists.resize(lists.size() + QUOTIENT_STAGE, 0);  // an LDG always reads entry 0 of its list: keep the tail readable
+}
+
+// Poseidon MDS layer on a window of 12 LDS registers (LCP2_OP_PMDS): the small-constant circulant on 32-bit halves with one
+// fold per element, exactly the layer of the hash kernels (poseidon.hpp), the 12 constants riding in the accumulators.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void q_pmds(u64 *lds, u32 T, u32 tid, u32 dst, u32 src, const_as<u64> add) {
+  const PosK k = pos_consts();
+  u32 lo[12], hi[12];
+  u64 rc[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) rc[j] = add[j];
+#pragma unroll
+  for (int j = 0; j < 12; j++) { const u64 v = lds[(src + j) * T + tid]; lo[j] = (u32)v; hi[j] = (u32)(v >> 32); }
+  pos_mds_h(lo, hi, rc, k);
+#pragma unroll
+  for (int j = 0; j < 12; j++) lds[(dst + j) * T + tid] = gl_canon(((u64)hi[j] << 32) | lo[j]);
+}
+__device__ __forceinline__ u64 q_sbox(u64 x) {
+  const PosK k = pos_consts();
+  u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  pos_sbox_h(x0, x1, k);
+  return gl_canon(((u64)x1 << 32) | x0);
+}
+#else  // host pass of hipcc: declarations only
+__device__ void q_pmds(u64 *lds, u32 T, u32 tid, u32 dst, u32 src, const_as<u64> add);
+__device__ u64 q_sbox(u64 x);
+#endif
+
+// ---- native PoseidonGate (LCP2_GATE_NATIVE_POSEIDON): plonky2 gates/poseidon.rs::eval_unfiltered_base with the state in
+// VGPRs (32-bit halves, lazily reduced, exactly the permutation of the hash kernels) instead of LDS registers and one
+// interpreted instruction at a time.  Wires: input 0..12, output 12..24, swap 24, delta 25..29, S-box inputs of full rounds
+// 1..3 at 29 + 12 (r - 1) + i, of the partial rounds at 65 + r, of full rounds 4..7 at 87 + 12 r + i.  The constraints come out
+// first to last; acc is the Horner chain with 1 / alpha (rescaled by the caller), as for every EMIT_FORWARD gate.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct QEmit {
+  u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
+  u32 CH, emitted;
+  __device__ __forceinline__ void operator()(u64 x) {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < CH) acc[c] = step[c] == 0 ? (emitted ? acc[c] : x) : gl_add(gl_mul(acc[c], step[c]), x);
+    emitted++;
+  }
+};
+__device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {
+  const PosK k = pos_consts();
+  const_as<u64> rc = konst(a.rc);
+  const u64 *W = a.wires + i;
+  const u64 st = a.stride;
+  u64 in[12], dl[4], swap;
+#pragma unroll
+  for (int j = 0; j < 12; j++) in[j] = W[(u64)j * st];
+  swap = W[24 * st];
+#pragma unroll
+  for (int j = 0; j < 4; j++) dl[j] = W[(u64)(25 + j) * st];
+  emit(gl_sub(gl_mul(swap, swap), swap));
+#pragma unroll
+  for (int j = 0; j < 4; j++) emit(gl_sub(gl_mul(swap, gl_sub(in[j + 4], in[j])), dl[j]));
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    u64 v = j < 4 ? gl_add(in[j], dl[j]) : j < 8 ? gl_sub(in[j], dl[j - 4]) : in[j];
+    v = gl_add_nc(v, rc[j]);
+    lo[j] = (u32)v; hi[j] = (u32)(v >> 32);
+  }
+  auto constrain12 = [&](u32 first_wire) {  // state - sbox_in for the 12 lanes, state <- sbox_in
+    u64 w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = W[(u64)(first_wire + j) * st];
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      emit(gl_sub(gl_canon(((u64)hi[j] << 32) | lo[j]), w[j]));
+      lo[j] = (u32)w[j]; hi[j] = (u32)(w[j] >> 32);
+    }
+  };
+  u32 round = 0;
+#pragma unroll 1
+  for (u32 r = 0; r < POS_FULL_HALF; r++, round++) {
+    if (r) constrain12(29 + 12 * (r - 1));
+#pragma unroll
+    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j], k);
+    u64 nxt[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) nxt[j] = rc[(round + 1) * 12 + j];
+    pos_mds_h(lo, hi, nxt, k);
+  }
+  // partial rounds: the 22 S-box wires are fetched in groups of QUOTIENT_STAGE through the staging slots (LDS)
+#pragma unroll 1
+  for (u32 r = 0; r < POS_PARTIAL; r++, round++) {
+    if (r % QUOTIENT_STAGE == 0) {
+      u64 pw[QUOTIENT_STAGE];
+#pragma unroll
+      for (u32 j = 0; j < QUOTIENT_STAGE; j++) pw[j] = W[(u64)(65 + min(r + j, (u32)POS_PARTIAL - 1)) * st];
+#pragma unroll
+      for (u32 j = 0; j < QUOTIENT_STAGE; j++) lds[(a.num_regs + j) * T + tid] = pw[j];
+    }
+    const u64 w = lds[(a.num_regs + (r % QUOTIENT_STAGE)) * T + tid];
+    emit(gl_sub(gl_canon(((u64)hi[0] << 32) | lo[0]), w));
+    lo[0] = (u32)w; hi[0] = (u32)(w >> 32);
+    pos_sbox_h(lo[0], hi[0], k);
+    u64 nxt[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) nxt[j] = rc[(round + 1) * 12 + j];
+    pos_mds_h(lo, hi, nxt, k);
+  }
+#pragma unroll 1
+  for (u32 r = 0; r < POS_FULL_HALF; r++, round++) {
+    constrain12(87 + 12 * r);
+#pragma unroll
+    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j], k);
+    u64 nxt[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) nxt[j] = round + 1 < POS_ROUNDS ? rc[(round + 1) * 12 + j] : 0;
+    pos_mds_h(lo, hi, nxt, k);
+  }
+  u64 out[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) out[j] = W[(u64)(12 + j) * st];
+#pragma unroll
+  for (int j = 0; j < 12; j++) emit(gl_sub(gl_canon(((u64)hi[j] << 32) | lo[j]), out[j]));
+}
+#endif
+
+// res[c] <- sum_g filter_g(point) * sum_i alpha_c^i constraint_{g,i}(point) for the point whose operands sit at index i
+__device__ __forceinline__ void q_eval_gates(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, u64 res[QUOTIENT_MAX_CH]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 CH = a.num_challenges;
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) res[c] = 0;
+  for (u32 g = 0; g < a.num_gates; g++) {
+    GateDev G;  // field by field: an address-space-qualified struct has no implicit copy
+    {
+      const_as<u32> gw = konst((const u32 *)a.gates) + (size_t)g * (sizeof(GateDev) / 4);
+      G.selector_index = gw[0]; G.selector_value = gw[1]; G.group_start = gw[2]; G.group_end = gw[3];
+      G.code_offset = gw[4]; G.code_len = gw[5]; G.num_constraints = gw[6]; G.flags = gw[7];
+    }
+    const bool fwd = (G.flags & LCP2_GATE_EMIT_FORWARD) != 0;
+    // Horner step with alpha (constraints listed last to first) or with 1 / alpha (first to last; rescaled below).
+    // alpha = 0 in a forward gate (step = 0): the sum is the first constraint alone.
+    QEmit emit;
+    emit.CH = CH; emit.emitted = 0;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { emit.acc[c] = 0; emit.step[c] = c < CH ? (fwd ? konst(a.alpha_inv)[c] : konst(a.alphas)[c]) : 0; }
+    if (a.use_native && (G.flags & LCP2_GATE_NATIVE_MASK) == LCP2_GATE_NATIVE_POSEIDON) {
+      q_poseidon_native(a, i, lds, T, tid, emit);
+    } else {
+      // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
+      // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
+      const_as<u64> code2 = konst((const u64 *)a.code);  // one instruction = two 32-bit words
+      u64 nxt = code2[G.code_offset];
+      for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
+        const u32 w0 = (u32)nxt, w1 = (u32)(nxt >> 32);
+        nxt = code2[pc + 1];
+        const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
+        if (op == QOP_LDG) { q_stage(a, dst, konst(a.stage_list) + w1, lds, T, tid, i); continue; }
+        if (op == LCP2_OP_PMDS) { q_pmds(lds, T, tid, dst, ia, konst(a.imm) + ib); continue; }
+        u64 x = q_operand(a, ka, ia, lds, T, tid, i);
+        if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
+          if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
+          if (fwd) emit(x);
+          else {  // step != 0 is not required here: plain Horner with alpha
+#pragma unroll
+            for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+              if (c < CH) emit.acc[c] = gl_add(gl_mul(emit.acc[c], emit.step[c]), x);
+          }
+          continue;
+        }
+        if (op == LCP2_OP_SBOX) { lds[dst * T + tid] = q_sbox(x); continue; }
+        u64 y = q_operand(a, kb, ib, lds, T, tid, i);
+        u64 r;
+        switch (op) {  // uniform across the wave: the code stream is the same for every point
+          case LCP2_OP_ADD: r = gl_add(x, y); break;
+          case LCP2_OP_SUB: r = gl_sub(x, y); break;
+          case LCP2_OP_MUL: r = gl_mul(x, y); break;
+          case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
+          case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
+          default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
+        }
+        lds[dst * T + tid] = r;
+      }
+    }
+    u64 s = a.consts[(u64)G.selector_index * a.stride + i];
+    u64 f = 1;
+    for (u32 j = G.group_start; j < G.group_end; j++)
+      if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
+    if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < CH) {
+        const u64 sum = (fwd && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
+        res[c] = gl_add(res[c], gl_mul(f, sum));
+      }
+  }
+#endif
 }
 
 __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
@@ -196,94 +468,142 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
   const u64 ig = a.leaf0 + i;
   const u32 CH = a.num_challenges;
   u64 res[QUOTIENT_MAX_CH];
-#pragma unroll
-  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) res[c] = 0;
 
   // ---- gate constraints: sum_g filter_g * sum_i alpha^i c_{g,i}
-  for (u32 g = 0; g < a.num_gates; g++) {
-    const GateDev G = a.gates[g];
-    u64 acc[QUOTIENT_MAX_CH];
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) acc[c] = 0;
-    // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
-    // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
-    const uint2 *code2 = (const uint2 *)a.code;
-    uint2 nxt = code2[G.code_offset];
-    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
-      const u32 w0 = nxt.x, w1 = nxt.y;
-      nxt = code2[pc + 1];
-      const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
-      u64 x = q_operand(a, ka, ia, lds, T, tid, i);
-      if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
-        if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
-#pragma unroll
-        for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-          if (c < CH) acc[c] = gl_add(gl_mul(acc[c], a.alphas[c]), x);
-        continue;
-      }
-      u64 y = q_operand(a, kb, ib, lds, T, tid, i);
-      u64 r;
-      switch (op) {  // uniform across the wave: the code stream is the same for every point
-        case LCP2_OP_ADD: r = gl_add(x, y); break;
-        case LCP2_OP_SUB: r = gl_sub(x, y); break;
-        case LCP2_OP_MUL: r = gl_mul(x, y); break;
-        case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
-        case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
-        default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
-      }
-      lds[dst * T + tid] = r;
-    }
-    u64 s = a.consts[(u64)G.selector_index * a.stride + i];
-    u64 f = 1;
-    for (u32 j = G.group_start; j < G.group_end; j++)
-      if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
-    if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) res[c] = gl_add(res[c], gl_mul(f, acc[c]));
-  }
+  q_eval_gates(a, i, lds, T, tid, res);
 
   // ---- permutation argument terms, folded in front of the gate constraints:
-  //   terms = [ L0 (Z_c - 1) ]_c ++ [ prev * prod num - next * prod den ]_{c,k} ; res <- sum_t alpha^t terms_t + alpha^nt * gates
+  //   terms = [ L0 (Z_c - 1) ]_c ++ [ prev * prod num - next * prod den ]_{c,k} ;  out = sum_t alpha^t terms_t + alpha^nt * gates
+  // The chunks are walked once for all challenges: the 8 wires and 8 sigmas of a batch and the next partial products are 18
+  // loads issued back to back (one HBM round trip per batch instead of one per column) and every column is read once.  The
+  // terms of challenge c2 then arrive first to last, so their block sum is a Horner chain with 1 / alpha, weighted afterwards
+  // by the power of alpha at which the block starts (alpha_pow: host table; alpha = 0 leaves term 0 alone, handled below).
   const u32 lgN = a.lgN;
   const u64 jnat = bitrev32((u32)ig, lgN);
   const u64 x = two_level(a.points, jnat);  // 7 * w_N^bitrev(ig)
   const u64 inext = bitrev32((u32)((jnat + (1u << a.rate_bits)) & (a.N - 1)), lgN) - a.leaf0;  // same coset = same leaf block
   const u32 npp = a.nchunks - 1;
-  // Horner from the last term down to the first, for every alpha
-  for (int c2 = (int)CH - 1; c2 >= 0; c2--) {
-    const u64 beta = a.betas[c2], gamma = a.gammas[c2];
-    const u64 bx = gl_mul(beta, x);
-    for (int k = (int)a.nchunks - 1; k >= 0; k--) {
-      u64 pn = 1, pd = 1;
-      for (u32 j = k * a.chunk; j < a.num_routed && j < (k + 1) * a.chunk; j++) {
-        u64 wg = gl_add(a.wires[(u64)j * a.stride + i], gamma);
-        pn = gl_mul(pn, gl_add(wg, gl_mul(bx, a.k_is[j])));
-        pd = gl_mul(pd, gl_add(wg, gl_mul(beta, a.consts[(u64)(a.num_constants + j) * a.stride + i])));
-      }
-      u64 prev = k == 0 ? a.zs[(u64)c2 * a.stride + i] : a.zs[((u64)CH + (u64)c2 * npp + (k - 1)) * a.stride + i];
-      u64 next = (u32)k < npp ? a.zs[((u64)CH + (u64)c2 * npp + k) * a.stride + i] : a.zs[(u64)c2 * a.stride + inext];
-      u64 term = gl_sub(gl_mul(prev, pn), gl_mul(next, pd));
+  u64 beta[QUOTIENT_MAX_CH], gamma[QUOTIENT_MAX_CH], bx[QUOTIENT_MAX_CH], prev[QUOTIENT_MAX_CH], z0[QUOTIENT_MAX_CH];
+  u64 hh[QUOTIENT_MAX_CH][QUOTIENT_MAX_CH];  // [c2][alpha challenge c]
+  u64 ainv[QUOTIENT_MAX_CH];
 #pragma unroll
-      for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-        if (c < CH) res[c] = gl_add(gl_mul(res[c], a.alphas[c]), term);
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+    beta[c] = c < CH ? konst(a.betas)[c] : 0; gamma[c] = c < CH ? konst(a.gammas)[c] : 0;
+    ainv[c] = c < CH ? konst(a.alpha_inv)[c] : 0;
+    bx[c] = gl_mul(beta[c], x);
+    z0[c] = c < CH ? a.zs[(u64)c * a.stride + i] : 0;
+    prev[c] = z0[c];
+#pragma unroll
+    for (u32 d = 0; d < QUOTIENT_MAX_CH; d++) hh[c][d] = 0;
+  }
+  for (u32 k = 0; k < a.nchunks; k++) {
+    u64 pn[QUOTIENT_MAX_CH], pd[QUOTIENT_MAX_CH], nx[QUOTIENT_MAX_CH];
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      pn[c] = 1; pd[c] = 1;
+      nx[c] = c < CH ? (k < npp ? a.zs[((u64)CH + (u64)c * npp + k) * a.stride + i] : a.zs[(u64)c * a.stride + inext]) : 0;
     }
+    const u32 jend = min((k + 1) * a.chunk, a.num_routed);
+    for (u32 j0 = k * a.chunk; j0 < jend; j0 += 8) {
+      u64 w[8], sg[8];
+#pragma unroll
+      for (u32 jj = 0; jj < 8; jj++) {  // lanes past the end of the chunk repeat its last column
+        const u32 j = min(j0 + jj, jend - 1);
+        w[jj] = a.wires[(u64)j * a.stride + i];
+        sg[jj] = a.consts[(u64)(a.num_constants + j) * a.stride + i];
+      }
+#pragma unroll
+      for (u32 jj = 0; jj < 8; jj++) {
+        if (j0 + jj < jend) {
+          const u64 kj = konst(a.k_is)[j0 + jj];
+#pragma unroll
+          for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+            if (c < CH) {
+              const u64 wg = gl_add(w[jj], gamma[c]);
+              pn[c] = gl_mul(pn[c], gl_add(wg, gl_mul(bx[c], kj)));
+              pd[c] = gl_mul(pd[c], gl_add(wg, gl_mul(beta[c], sg[jj])));
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (u32 c2 = 0; c2 < QUOTIENT_MAX_CH; c2++)
+      if (c2 < CH) {
+        const u64 term = gl_sub(gl_mul(prev[c2], pn[c2]), gl_mul(nx[c2], pd[c2]));
+        prev[c2] = nx[c2];
+#pragma unroll
+        for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+          if (c < CH) hh[c2][c] = gl_add(gl_mul(hh[c2][c], ainv[c]), term);
+      }
   }
   const u64 l0 = a.l0[ig];
-  for (int c2 = (int)CH - 1; c2 >= 0; c2--) {
-    u64 term = gl_mul(l0, gl_sub(a.zs[(u64)c2 * a.stride + i], 1));
 #pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) res[c] = gl_add(gl_mul(res[c], a.alphas[c]), term);
-  }
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+    if (c < CH) {
+      const_as<u64> pw = konst(a.alpha_pow) + c * QUOTIENT_ALPHA_POWS;
+      u64 l0t[QUOTIENT_MAX_CH];
+#pragma unroll
+      for (u32 c2 = 0; c2 < QUOTIENT_MAX_CH; c2++) l0t[c2] = c2 < CH ? gl_mul(l0, gl_sub(z0[c2], 1)) : 0;
+      if (ainv[c] == 0) { res[c] = l0t[0]; continue; }  // alpha = 0: only the term of weight alpha^0 survives
+      u64 r = gl_mul(res[c], pw[CH + CH * a.nchunks]);
+#pragma unroll
+      for (u32 c2 = 0; c2 < QUOTIENT_MAX_CH; c2++)
+        if (c2 < CH) {
+          r = gl_add(r, gl_mul(hh[c2][c], pw[CH + c2 * a.nchunks + a.nchunks - 1]));
+          r = gl_add(r, gl_mul(l0t[c2], pw[c2]));
+        }
+      res[c] = r;
+    }
   const u64 zhi = a.zh_inv[ig >> (lgN - a.rate_bits)];
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
     if (c < CH) a.out[(u64)c * a.N + ig] = gl_mul(res[c], zhi);
 }
 void launch_quotient(hipStream_t s, const QuotientArgs &a) {
-  size_t lds = (size_t)a.num_regs * QUOTIENT_THREADS * sizeof(u64);
+  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);  // the programs' registers + the operand staging slots
   hipLaunchKernelGGL(k_quotient, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a);
+}
+
+// The gate programs over the rows of H: on a row only its own gate has a non-zero filter, so the filtered combination is
+// zero for every alpha exactly when that gate's constraints hold there (up to the 2^-64 chance of a bad alpha).
+__global__ __launch_bounds__(QUOTIENT_THREADS) void k_gate_check(QuotientArgs a, unsigned long long *flag) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
+  const u64 i = (u64)blockIdx.x * T + tid;
+  if (i >= a.count) return;
+  u64 res[QUOTIENT_MAX_CH];
+  q_eval_gates(a, i, lds, T, tid, res);
+  bool bad = false;
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+    if (c < a.num_challenges && res[c] != 0) bad = true;
+  if (bad) atomicMin(flag, (unsigned long long)i + 1);
+}
+// build()-time check of the native evaluators against the programs they claim to be (random points in a.wires / a.consts)
+__global__ __launch_bounds__(QUOTIENT_THREADS) void k_native_check(QuotientArgs a, unsigned long long *flag) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
+  const u64 i = (u64)blockIdx.x * T + tid;
+  if (i >= a.count) return;
+  u64 r0[QUOTIENT_MAX_CH], r1[QUOTIENT_MAX_CH];
+  QuotientArgs b = a;
+  b.use_native = 0;
+  q_eval_gates(b, i, lds, T, tid, r0);
+  b.use_native = 1;
+  q_eval_gates(b, i, lds, T, tid, r1);
+  bool bad = false;
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+    if (c < a.num_challenges && r0[c] != r1[c]) bad = true;
+  if (bad) atomicMin(flag, (unsigned long long)i + 1);
+}
+void launch_native_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag) {
+  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  hipLaunchKernelGGL(k_native_check, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a, flag);
+}
+void launch_gate_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag) {
+  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  hipLaunchKernelGGL(k_gate_check, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a, flag);
 }
 
 // ------------------------------------------------------------------ K7a: evaluate coefficient polynomials at an extension point

@@ -15,7 +15,7 @@ using namespace lcp2;
 struct lcp2_circuit {
   lcp2_ctx *ctx = nullptr;
   lcp2_params p{};
-  uint32_t npi = 0, num_selectors = 0, num_regs = 1;
+  uint32_t npi = 0, num_selectors = 0, num_regs = 1, dev_regs = 1;
   std::vector<lcp2_gate> gates;
   std::vector<uint32_t> code;
   std::vector<u64> imm, k_is;
@@ -23,7 +23,7 @@ struct lcp2_circuit {
   std::vector<u64> cs_cap;
   u64 last_challenges[97] = {0};
   // device: description
-  DevBuf d_gates, d_code, d_imm, d_kis, d_l0, d_zh_inv, cs_values;
+  DevBuf d_gates, d_code, d_stage, d_imm, d_kis, d_l0, d_zh_inv, cs_values;
   lcp2_oracle cs;  // constants_sigmas commitment
   // device: per-proof workspace (allocated once)
   lcp2_oracle wires, zs, quot;
@@ -48,23 +48,38 @@ struct lcp2_circuit {
 namespace {
 #define LCP2_TRY(expr) do { int rc_ = (expr); if (rc_ != LCP2_OK) return rc_; } while (0)
 
+// word offsets inside lcp2_circuit::small (per-proof scalars on the device)
+constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
+                 SMALL_CHECK = 21, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
+
 inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
 
-int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
-  if (p.degree_bits < 1 || p.degree_bits + p.rate_bits > 30) return ctx->fail(LCP2_E_INVALID, "degree_bits out of range");
-  if (p.quotient_degree_factor != (1u << p.rate_bits)) return ctx->fail(LCP2_E_UNSUPPORTED, "quotient_degree_factor must equal 2^rate_bits");
-  if (p.num_challenges < 1 || p.num_challenges > QUOTIENT_MAX_CH) return ctx->fail(LCP2_E_UNSUPPORTED, "num_challenges must be 1 or 2");
-  if (p.num_routed_wires > p.num_wires || p.num_routed_wires == 0) return ctx->fail(LCP2_E_INVALID, "bad routed wire count");
-  if ((p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor > PERM_MAX_CHUNKS) return ctx->fail(LCP2_E_UNSUPPORTED, "too many routed wires");
-  if (p.cap_height > p.degree_bits + p.rate_bits) return ctx->fail(LCP2_E_INVALID, "cap_height exceeds the LDE tree");
-  if (p.num_query_rounds > 64 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS) return ctx->fail(LCP2_E_UNSUPPORTED, "too many queries / layers");
-  if (p.proof_of_work_bits < 1 || p.proof_of_work_bits > 40) return ctx->fail(LCP2_E_UNSUPPORTED, "proof_of_work_bits out of range");
+// shape checks shared by build() and the verifier-only constructor: everything the prover's workspaces and the verifier's
+// fixed-size arrays rely on.  Returns nullptr or the reason; *unsupported says which status it is.
+const char *params_problem(const lcp2_params &p, bool *unsupported) {
+  *unsupported = false;
+  if (p.degree_bits < 1 || p.rate_bits < 1 || p.rate_bits > 8 || p.degree_bits + p.rate_bits > 30) return "degree_bits / rate_bits out of range";
+  if (p.num_wires == 0 || p.num_wires > 65535 || p.num_constants > 65535) return "bad column counts";
+  if (p.num_routed_wires > p.num_wires || p.num_routed_wires == 0) return "bad routed wire count";
+  if (p.cap_height > p.degree_bits + p.rate_bits) return "cap_height exceeds the LDE tree";
+  *unsupported = true;
+  if (p.quotient_degree_factor != (1u << p.rate_bits)) return "quotient_degree_factor must equal 2^rate_bits";
+  if (p.num_challenges < 1 || p.num_challenges > QUOTIENT_MAX_CH) return "num_challenges must be 1 or 2";
+  if ((p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor > PERM_MAX_CHUNKS) return "too many routed wires";
+  if (p.num_query_rounds > 64 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS) return "too many queries / layers";
+  if (p.proof_of_work_bits < 1 || p.proof_of_work_bits > 40) return "proof_of_work_bits out of range";
+  *unsupported = false;
   u32 lg = p.degree_bits + p.rate_bits, d = p.degree_bits;
   for (u32 l = 0; l < p.num_fri_layers; l++) {
     u32 ab = p.fri_arity_bits[l];
-    if (ab < 1 || ab > 5 || ab > d || lg - ab < p.cap_height) return ctx->fail(LCP2_E_INVALID, "bad FRI arity schedule");
+    if (ab < 1 || ab > 5 || ab > d || lg - ab < p.cap_height) return "bad FRI arity schedule";
     lg -= ab; d -= ab;
   }
+  return nullptr;
+}
+int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
+  bool unsupported;
+  if (const char *why = params_problem(p, &unsupported)) return ctx->fail(unsupported ? LCP2_E_UNSUPPORTED : LCP2_E_INVALID, why);
   return LCP2_OK;
 }
 
@@ -96,21 +111,36 @@ void ext_pow_tables(gl2 z, u32 h, u64 hi_count, std::vector<u64> &out, size_t &l
 static const char *validate_programs(const lcp2_circuit_desc *d) {
   const lcp2_params &p = d->params;
   if (d->num_regs > 64 || d->num_selectors > p.num_constants) return "bad gate set";
+  const size_t nregs = std::max(d->num_regs, 1u);
   for (u32 g = 0; g < d->num_gates; g++) {
     const lcp2_gate &G = d->gates[g];
-    if (G.selector_index >= d->num_selectors || (size_t)(G.code_offset + G.code_len) * 2 > d->code_words || G.group_end < G.group_start)
+    if (G.selector_index >= d->num_selectors || ((size_t)G.code_offset + (size_t)G.code_len) * 2 > d->code_words || G.group_end < G.group_start ||
+        (G.flags & ~(LCP2_GATE_EMIT_FORWARD | LCP2_GATE_NATIVE_MASK)))
       return "gate descriptor out of range";
-    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
+    if ((G.flags & LCP2_GATE_NATIVE_MASK) != 0) {
+      if ((G.flags & LCP2_GATE_NATIVE_MASK) != LCP2_GATE_NATIVE_POSEIDON) return "unknown native gate id";
+      if (!(G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints != 123 || p.num_wires < 135) return "LCP2_GATE_NATIVE_POSEIDON needs 135 wires, 123 forward-emitted constraints";
+    }
+    size_t emits_seen = 0;
+    for (size_t pc = G.code_offset; pc < (size_t)G.code_offset + G.code_len; pc++) {
       u32 w0 = d->code[2 * pc], w1 = d->code[2 * pc + 1];
       u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, kk[2] = {(w0 >> 16) & 0xF, (w0 >> 20) & 0xF}, ii[2] = {w1 & 0xFFFF, w1 >> 16};
       const bool emits = op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL;
-      if (op > LCP2_OP_MULADD || (!emits && dst >= std::max(d->num_regs, 1u))) return "bad instruction";
-      for (int s = 0; s < (emits ? 1 : 2); s++) {
-        u32 lim = kk[s] == 0 ? std::max(d->num_regs, 1u) : kk[s] == 1 ? p.num_wires : kk[s] == 2 ? p.num_constants - d->num_selectors
-                  : kk[s] == 3 ? (u32)d->num_imm : kk[s] == 4 ? d->num_public_inputs : 0;
-        if (ii[s] >= lim) return "operand out of range";
+      if (op > LCP2_OP_PMDS) return "bad instruction";
+      if (op == LCP2_OP_PMDS) {  // register windows of 12 and a block of 12 immediates
+        if (kk[0] != 0 || kk[1] != 3 || (size_t)dst + 12 > nregs || (size_t)ii[0] + 12 > nregs || (size_t)ii[1] + 12 > d->num_imm) return "PMDS window out of range";
+        continue;
+      }
+      if (!emits && dst >= nregs) return "bad instruction";
+      emits_seen += emits;
+      const int nsrc = (emits || op == LCP2_OP_SBOX) ? 1 : 2;
+      for (int k = 0; k < nsrc; k++) {
+        size_t lim = kk[k] == 0 ? nregs : kk[k] == 1 ? p.num_wires : kk[k] == 2 ? p.num_constants - d->num_selectors
+                     : kk[k] == 3 ? d->num_imm : kk[k] == 4 ? 4 : 0;
+        if (ii[k] >= lim) return "operand out of range";
       }
     }
+    if (emits_seen != G.num_constraints) return "num_constraints does not match the program";
   }
   return nullptr;
 }
@@ -125,6 +155,60 @@ static int download_cap(lcp2_circuit *c, const lcp2_oracle &o, u64 *dst) {
   return download(c->ctx, dst + c->bf * per_block, o.cap_dev(), per_block * c->bc * 8);
 }
 
+// circuit_builder.rs::build: circuit_digest = hash_no_pad(constants_sigmas_cap || domain_separator_digest || degree_bits) with
+// domain_separator_digest = hash_pad(domain separator), the separator empty unless the builder sets one: pad10*1 = [1, 0 x 6, 1]
+static void circuit_digest(const std::vector<u64> &cs_cap, u32 degree_bits, u64 digest[4]) {
+  std::vector<u64> buf(cs_cap);
+  const u64 empty_padded[8] = {1, 0, 0, 0, 0, 0, 0, 1};
+  u64 ds[4];
+  HostPoseidon::get().hash_no_pad(empty_padded, 8, ds);
+  buf.insert(buf.end(), ds, ds + 4);
+  buf.push_back(degree_bits);
+  HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), digest);
+}
+
+// The LCP2_GATE_NATIVE_* claims of the description, checked on the device: program and native evaluator on 256 random points
+// (a polynomial identity in 135 + NC variables of degree <= 9: a wrong claim survives with probability ~2^-60).
+static int check_native_gates(lcp2_circuit *c) {
+  lcp2_ctx *ctx = c->ctx;
+  bool any = false;
+  for (const lcp2_gate &G : c->gates) any = any || (G.flags & LCP2_GATE_NATIVE_MASK);
+  if (!any) return LCP2_OK;
+  const lcp2_params &p = c->p;
+  const u64 cnt = 256;
+  u64 seed = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { seed += 0x9E3779B97F4A7C15ull; u64 z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return gl_canon(z ^ (z >> 31)); };
+  std::vector<u64> hw((size_t)p.num_wires * cnt), hc((size_t)p.num_constants * cnt), hs(SMALL_GATE_SCALE + (size_t)QUOTIENT_MAX_CH * c->gates.size(), 0);
+  for (auto &v : hw) v = rnd();
+  for (auto &v : hc) v = rnd();
+  for (u32 k = 0; k < p.num_challenges; k++) {
+    const u64 al = rnd() | 1;
+    hs[SMALL_ALPHAS + k] = gl_canon(al);
+    hs[SMALL_ALPHA_INV + k] = gl_inv(gl_canon(al));
+    for (size_t g = 0; g < c->gates.size(); g++)
+      hs[SMALL_GATE_SCALE + g * QUOTIENT_MAX_CH + k] = c->gates[g].num_constraints ? gl_pow(gl_canon(al), c->gates[g].num_constraints - 1) : 1;
+  }
+  for (u32 i = 0; i < 4; i++) hs[SMALL_PI_HASH + i] = rnd();
+  hs[SMALL_CHECK] = ~0ull;
+  DevBuf dw, dc;
+  LCP2_TRY(upload(ctx, dw, hw.data(), hw.size() * 8));
+  LCP2_TRY(upload(ctx, dc, hc.data(), hc.size() * 8));
+  LCP2_HIP(ctx, hipMemcpyAsync(c->small.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  QuotientArgs a{};
+  u64 *d_small = c->small.u();
+  a.wires = dw.u(); a.consts = dc.u(); a.stride = cnt; a.count = cnt;
+  a.alphas = d_small + SMALL_ALPHAS; a.alpha_inv = d_small + SMALL_ALPHA_INV; a.pis = d_small + SMALL_PI_HASH; a.gate_scale = d_small + SMALL_GATE_SCALE;
+  a.imm = c->d_imm.u(); a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.stage_list = (const u32 *)c->d_stage.p;
+  a.num_wires = p.num_wires; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors; a.num_constants = p.num_constants;
+  a.num_challenges = p.num_challenges; a.num_regs = c->num_regs; a.rc = ctx->d_rc;
+  launch_native_check(ctx->stream, a, (unsigned long long *)(d_small + SMALL_CHECK));
+  LCP2_HIP(ctx, hipGetLastError());
+  u64 bad = 0;
+  LCP2_TRY(download(ctx, &bad, d_small + SMALL_CHECK, 8));
+  if (bad != ~0ull) return ctx->fail(LCP2_E_INVALID, "a gate flagged LCP2_GATE_NATIVE_* does not compute what its program computes");
+  return LCP2_OK;
+}
+
 static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf, uint32_t bc, lcp2_circuit **out) {
   if (!ctx || !d || !out) return LCP2_E_INVALID;
   *out = nullptr;
@@ -132,7 +216,7 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   LCP2_TRY(check_params(ctx, d->params));
   const lcp2_params &p = d->params;
   if (d->num_selectors > p.num_constants || d->num_regs > 64 || d->num_gates == 0) return ctx->fail(LCP2_E_INVALID, "bad gate set");
-  if (d->num_public_inputs > 4096) return ctx->fail(LCP2_E_UNSUPPORTED, "too many public inputs");
+  if (d->num_public_inputs > (1u << 20)) return ctx->fail(LCP2_E_UNSUPPORTED, "too many public inputs");
   if (const char *why = validate_programs(d)) return ctx->fail(LCP2_E_INVALID, why);
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
   std::unique_ptr<lcp2_circuit> c(new lcp2_circuit());
@@ -151,11 +235,31 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   for (u32 i = 0; i < p.num_routed_wires; i++) c->k_is[i] = gl_canon(d->k_is[i]);
   const u64 n = 1ull << p.degree_bits, N = n << p.rate_bits;
   const u32 ncs = p.num_constants + p.num_routed_wires, CH = p.num_challenges, npp = npp_of(p), nchunks = npp + 1;
-  LCP2_TRY(upload(ctx, c->d_gates, c->gates.data(), c->gates.size() * sizeof(lcp2_gate)));
-  {  // padded by two instructions: K6 fetches one instruction ahead of the one it executes
-    std::vector<uint32_t> padded(c->code);
-    padded.resize(padded.size() + 4, 0);
-    LCP2_TRY(upload(ctx, c->d_code, padded.data(), padded.size() * 4));
+  {  // the device runs the staged form of the programs (prover_kernels.hpp); the verifier keeps the caller's form
+    static_assert(sizeof(GateDev) == sizeof(lcp2_gate), "GateDev mirrors lcp2_gate");
+    std::vector<GateDev> dev_gates(c->gates.size());
+    memcpy(dev_gates.data(), c->gates.data(), c->gates.size() * sizeof(lcp2_gate));
+    std::vector<uint32_t> staged, lists;
+    stage_gate_programs(c->code, dev_gates, p.num_wires, c->num_selectors, staged, lists);
+    // LDS registers the DEVICE needs: programs that run natively never touch them (their count is only a verifier matter)
+    c->dev_regs = 1;
+    for (const lcp2_gate &G : c->gates) {
+      if (G.flags & LCP2_GATE_NATIVE_MASK) continue;
+      for (size_t pc = G.code_offset; pc < (size_t)G.code_offset + G.code_len; pc++) {
+        const u32 w0 = c->code[2 * pc], w1 = c->code[2 * pc + 1], op = w0 & 0xF, dst = (w0 >> 8) & 0xFF;
+        const bool emits = op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL;
+        u32 top = emits ? 0 : dst + (op == LCP2_OP_PMDS ? 12 : 1);
+        if (((w0 >> 16) & 0xF) == 0 && op != LCP2_OP_PMDS) top = std::max(top, (w1 & 0xFFFF) + 1);
+        if (op == LCP2_OP_PMDS) top = std::max(top, (w1 & 0xFFFF) + 12);
+        if (!emits && op != LCP2_OP_SBOX && op != LCP2_OP_PMDS && ((w0 >> 20) & 0xF) == 0) top = std::max(top, (w1 >> 16) + 1);
+        c->dev_regs = std::max(c->dev_regs, top);
+      }
+    }
+    staged.resize(staged.size() + 4, 0);  // padded by two instructions: K6 fetches one instruction ahead of the one it executes
+    LCP2_TRY(upload(ctx, c->d_gates, dev_gates.data(), dev_gates.size() * sizeof(GateDev)));
+    LCP2_TRY(upload(ctx, c->d_code, staged.data(), staged.size() * 4));
+    LCP2_TRY(upload(ctx, c->d_stage, lists.data(), lists.size() * 4));
+    LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
   }
   LCP2_TRY(upload(ctx, c->d_imm, c->imm.data(), c->imm.size() * 8));
   LCP2_TRY(upload(ctx, c->d_kis, c->k_is.data(), c->k_is.size() * 8));
@@ -167,11 +271,7 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   const size_t capw = (size_t)4 << p.cap_height;
   c->cs_cap.resize(capw);
   LCP2_TRY(download_cap(c.get(), c->cs, c->cs_cap.data()));
-  if (!c->sharded()) {  // circuit digest = H(constants_sigmas_cap || degree_bits); sharded: lcp2_circuit_set_constants_cap
-    std::vector<u64> buf(c->cs_cap);
-    buf.push_back(p.degree_bits);
-    HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), c->digest);
-  }
+  if (!c->sharded()) circuit_digest(c->cs_cap, p.degree_bits, c->digest);  // sharded: lcp2_circuit_set_constants_cap
   // L_0 on the LDE points (leaf order): LDE of the polynomial with all coefficients 1/n
   {
     DevBuf ones;
@@ -200,7 +300,7 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   LCP2_HIP(ctx, c->scan_tmp.alloc(std::max(scan_scratch_words(n, 4), (u64)16) * 8));
   LCP2_HIP(ctx, c->qvals.alloc((size_t)CH * N * 8));
   LCP2_HIP(ctx, c->planes.alloc((size_t)4 * n * 8));
-  LCP2_HIP(ctx, c->small.alloc(4096 * 8));
+  LCP2_HIP(ctx, c->small.alloc((SMALL_GATE_SCALE + (size_t)QUOTIENT_MAX_CH * d->num_gates + 8) * 8));
   {
     u32 maxcols = std::max(std::max(ncs, p.num_wires), std::max(CH * (1 + npp), CH * p.quotient_degree_factor));
     u64 nchk = (n + EVAL_CHUNK - 1) / EVAL_CHUNK;
@@ -230,6 +330,7 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   LCP2_HIP(ctx, c->q_idx.alloc(64 * 8 * (2 + LCP2_MAX_FRI_LAYERS)));
   LCP2_HIP(ctx, c->q_buf.alloc((size_t)64 * (ncs + p.num_wires + CH * (1 + npp) + CH * p.quotient_degree_factor + 4 * 4 * 32 + LCP2_MAX_FRI_LAYERS * (64 + 4 * 32)) * 8));
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LCP2_TRY(check_native_gates(c.get()));
   *out = c.release();
   return LCP2_OK;
 }
@@ -248,9 +349,7 @@ extern "C" int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *c
   if (memcmp(cap + c->bf * per_block, c->cs_cap.data() + c->bf * per_block, per_block * c->bc * 8) != 0)
     return c->ctx->fail(LCP2_E_INVALID, "constants cap does not contain this shard's entries");
   c->cs_cap.assign((const u64 *)cap, (const u64 *)cap + capw);
-  std::vector<u64> buf(c->cs_cap);
-  buf.push_back(c->p.degree_bits);
-  HostPoseidon::get().hash_no_pad(buf.data(), buf.size(), c->digest);
+  circuit_digest(c->cs_cap, c->p.degree_bits, c->digest);
   c->cap_final = true;
   return LCP2_OK;
 }
@@ -259,9 +358,9 @@ extern "C" int lcp2_verifier_create(const lcp2_circuit_desc *d, const uint64_t d
   if (!d || !digest || !cap || !out || !d->k_is || !d->gates || !d->code) return LCP2_E_INVALID;
   *out = nullptr;
   const lcp2_params &p = d->params;
-  if (p.num_challenges < 1 || p.num_challenges > 4 || p.num_fri_layers > LCP2_MAX_FRI_LAYERS || p.num_query_rounds > 64 ||
-      p.num_routed_wires > p.num_wires || d->num_selectors > p.num_constants)
-    return LCP2_E_INVALID;
+  bool unsupported;
+  if (params_problem(p, &unsupported)) return unsupported ? LCP2_E_UNSUPPORTED : LCP2_E_INVALID;  // the verifier indexes fixed-size arrays by these
+  if (d->num_selectors > p.num_constants || d->num_gates == 0 || (d->num_imm && !d->imm)) return LCP2_E_INVALID;
   if (validate_programs(d)) return LCP2_E_INVALID;
   lcp2_circuit *c = new lcp2_circuit();
   c->p = p; c->npi = d->num_public_inputs; c->num_selectors = d->num_selectors; c->num_regs = std::max(d->num_regs, 1u);
@@ -381,7 +480,7 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
   if (c->stage < lcp2_circuit::ST_WIRES) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
   const u64 *d_wires = c->d_wires_cur;
   u64 *d_small = c->small.u();
-  u64 *d_betas = d_small, *d_gammas = d_small + 4;
+  u64 *d_betas = d_small + SMALL_BETAS, *d_gammas = d_small + SMALL_GAMMAS;
   u64 bc[4] = {0}, gc[4] = {0};
   for (u32 k = 0; k < CH; k++) { bc[k] = gl_canon(betas[k]); gc[k] = gl_canon(gammas[k]); }
   LCP2_HIP(ctx, hipMemcpyAsync(d_betas, bc, CH * 8, hipMemcpyHostToDevice, s));
@@ -401,44 +500,72 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
     launch_perm_finalize(s, a);
   }
   LCP2_HIP(ctx, hipGetLastError());
+  // Copy constraints: Z must come back to 1 after the last row, Z(g^(n-1)) * (row n-1's quotient) = 1, which holds for
+  // every beta, gamma exactly when the wire values are constant on the cycles of sigma (up to the soundness error of the
+  // argument itself).  plonky2 reports a broken copy constraint as an Err of prove(); so does this (LCP2_E_UNSAT).
+  u64 wrap[2 * QUOTIENT_MAX_CH];
+  for (u32 k = 0; k < CH; k++) {
+    LCP2_HIP(ctx, hipMemcpyAsync(&wrap[2 * k], c->zs_vals.u() + (u64)k * n + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    LCP2_HIP(ctx, hipMemcpyAsync(&wrap[2 * k + 1], c->row_tot.u() + (u64)k * n + (n - 1), 8, hipMemcpyDeviceToHost, s));
+  }
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
-  LCP2_TRY(download_cap(c, c->zs, cap_out));
+  LCP2_TRY(download_cap(c, c->zs, cap_out));  // synchronises the stream: `wrap` has landed
+  for (u32 k = 0; k < CH; k++)
+    if (gl_mul(wrap[2 * k], wrap[2 * k + 1]) != 1) return ctx->fail(LCP2_E_UNSAT, "the witness violates a copy constraint (the permutation product does not return to 1)");
   c->stage = lcp2_circuit::ST_ZS;
   return LCP2_OK;
 }
 
 // compute_quotient_polys + commitment (K6, K1-K4)
-int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs) {
+int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash) {
   LCP2_STAGE_PROLOGUE
   if (c->stage < lcp2_circuit::ST_ZS) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
   u64 *d_small = c->small.u();
-  u64 *d_betas = d_small, *d_gammas = d_small + 4, *d_alphas = d_small + 8, *d_pis = d_small + 16;
-  std::vector<u64> pis(std::max<u32>(c->npi, 1), 0);
-  for (u32 i = 0; i < c->npi; i++) pis[i] = gl_canon(public_inputs[i]);
-  u64 ac[4] = {0};
-  for (u32 k = 0; k < CH; k++) ac[k] = gl_canon(alphas[k]);
-  if (c->npi) LCP2_HIP(ctx, hipMemcpyAsync(d_pis, pis.data(), c->npi * 8, hipMemcpyHostToDevice, s));
-  LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, ac, CH * 8, hipMemcpyHostToDevice, s));
-  LCP2_HIP(ctx, hipStreamSynchronize(s));
+  u64 *d_betas = d_small + SMALL_BETAS, *d_gammas = d_small + SMALL_GAMMAS, *d_alphas = d_small + SMALL_ALPHAS;
+  const u32 NG = (u32)c->gates.size();
+  {  // alphas, their inverses, the public-input hash, the check flag and alpha^(m_g - 1) per gate: one small upload
+    std::vector<u64> h(SMALL_GATE_SCALE - SMALL_ALPHAS + (size_t)QUOTIENT_MAX_CH * NG, 0);
+    for (u32 k = 0; k < CH; k++) {
+      const u64 al = gl_canon(alphas[k]);
+      h[k] = al;
+      h[SMALL_ALPHA_INV - SMALL_ALPHAS + k] = al ? gl_inv(al) : 0;
+      for (u32 g = 0; g < NG; g++)
+        h[SMALL_GATE_SCALE - SMALL_ALPHAS + (size_t)g * QUOTIENT_MAX_CH + k] = c->gates[g].num_constraints ? gl_pow(al, c->gates[g].num_constraints - 1) : 1;
+      u64 pw = 1;
+      for (u32 e = 0; e < QUOTIENT_ALPHA_POWS; e++) { h[SMALL_ALPHA_POW - SMALL_ALPHAS + (size_t)k * QUOTIENT_ALPHA_POWS + e] = pw; pw = gl_mul(pw, al); }
+    }
+    for (u32 i = 0; i < 4; i++) h[SMALL_PI_HASH - SMALL_ALPHAS + i] = gl_canon(pi_hash[i]);
+    h[SMALL_CHECK - SMALL_ALPHAS] = ~0ull;
+    LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
+    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `h` is a stack-lifetime staging buffer
+  }
   // ---- K6: quotient values on the coset, coset iNTT, chunking, commitment
   {
     QuotientArgs a{};
     a.wires = c->wires.lde.u(); a.consts = c->cs.lde.u(); a.zs = c->zs.lde.u(); a.l0 = c->d_l0.u(); a.zh_inv = c->d_zh_inv.u();
     u64 ls, hs;
     a.points = ntt.shift_table(gl_root_of_unity(lgN), lgN, 0, false, GL_GENERATOR, ls, hs);
-    a.k_is = c->d_kis.u(); a.betas = d_betas; a.gammas = d_gammas; a.alphas = d_alphas; a.pis = d_pis; a.imm = c->d_imm.u();
+    a.k_is = c->d_kis.u(); a.betas = d_betas; a.gammas = d_gammas; a.alphas = d_alphas; a.pis = d_small + SMALL_PI_HASH; a.imm = c->d_imm.u();
+    a.alpha_inv = d_small + SMALL_ALPHA_INV; a.gate_scale = d_small + SMALL_GATE_SCALE; a.alpha_pow = d_small + SMALL_ALPHA_POW;
     a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.out = c->qvals.u();
-    a.N = N; a.lgN = lgN; a.rate_bits = p.rate_bits; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors;
-    a.num_constants = NC; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH; a.num_regs = c->num_regs;
+    a.stage_list = (const u32 *)c->d_stage.p; a.num_wires = W; a.use_native = 1; a.rc = ctx->d_rc;
+    a.N = N; a.lgN = lgN; a.rate_bits = p.rate_bits; a.num_gates = NG; a.num_selectors = c->num_selectors;
+    a.num_constants = NC; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH; a.num_regs = c->dev_regs;
     a.leaf0 = (u64)c->bf * n; a.count = (u64)c->nblocks() * n; a.stride = a.count;
     if (be.status) return be.status;
     // a sharded circuit fills its own leaf blocks and leaves zeros elsewhere: the ranks' buffers sum (or OR) to the values
     if (c->sharded()) LCP2_HIP(ctx, hipMemsetAsync(c->qvals.p, 0, (size_t)CH * N * 8, s));
-    ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)a.count * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH));
+    ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)a.count * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH) + 8.0 * n * (W + NC));
+    // the gate constraints on the n rows of H first (1/8 of the work below): a witness that violates one is the Err of prove()
+    QuotientArgs h = a;
+    h.wires = c->d_wires_cur; h.consts = c->cs_values.u(); h.leaf0 = 0; h.count = n; h.stride = n;
+    launch_gate_check(s, h, (unsigned long long *)(d_small + SMALL_CHECK));
     launch_quotient(s, a);
   }
   LCP2_HIP(ctx, hipGetLastError());
-  LCP2_HIP(ctx, hipStreamSynchronize(s));
+  u64 bad_row = ~0ull;
+  LCP2_TRY(download(ctx, &bad_row, d_small + SMALL_CHECK, 8));  // synchronises the stream
+  if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1));
   c->stage = lcp2_circuit::ST_QVALS;
   return LCP2_OK;
 }
@@ -460,9 +587,9 @@ int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
   return LCP2_OK;
 }
 
-int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *public_inputs, u64 *cap_out) {
+int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash, u64 *cap_out) {
   if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: use lcp2_quotient_values, exchange the buffer, then lcp2_quotient_commit");
-  LCP2_TRY(stage_quotient_values(c, alphas, public_inputs));
+  LCP2_TRY(stage_quotient_values(c, alphas, pi_hash));
   return stage_quotient_commit(c, cap_out);
 }
 
@@ -581,7 +708,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     PowArgs a{};
     ch.pow_state(a.state, a.pos);
     a.bits = p.proof_of_work_bits; a.rc = ctx->d_rc;
-    u64 *d_res = c->small.u() + 1024;
+    u64 *d_res = c->small.u() + SMALL_POW;
     a.result = d_res;
     const u64 batch = 1ull << 20;
     u64 res = ~0ull;
@@ -674,9 +801,12 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
 }
 }  // namespace
 
-extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, uint64_t *proof_) {
+extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem wires_mem, const uint64_t *public_inputs_, size_t num_public_inputs,
+                          uint64_t *proof_, size_t proof_words) {
   if (!c || !wires_in_ || !proof_ || (c->npi && !public_inputs_)) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;  // verifier-only circuit
+  if (num_public_inputs != c->npi) return c->ctx->fail(LCP2_E_INVALID, "lcp2_prove: public input count does not match the circuit");
+  if (proof_words != ProofLayout(c->p).total) return c->ctx->fail(LCP2_E_INVALID, "lcp2_prove: proof buffer is not lcp2_proof_words() long");
   if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: drive the stages and their exchange steps (parallel.py ShardedProver)");
   const u64 *public_inputs = (const u64 *)public_inputs_;
   u64 *proof = (u64 *)proof_;
@@ -701,7 +831,7 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   LCP2_TRY(stage_perm_zs(c, betas, gammas, proof + L.zs_cap));
   ch.observe_n(proof + L.zs_cap, L.capw);
   for (u32 k = 0; k < CH; k++) alphas[k] = ch.get();
-  LCP2_TRY(stage_quotient(c, alphas, pis.data(), proof + L.quot_cap));
+  LCP2_TRY(stage_quotient(c, alphas, pi_hash, proof + L.quot_cap));
   ch.observe_n(proof + L.quot_cap, L.capw);
   const gl2 zeta = ch.get_ext();
   gl2 alpha, fri_betas[LCP2_MAX_FRI_LAYERS];
@@ -731,15 +861,15 @@ extern "C" int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64
   if (!c->ctx) return LCP2_E_NODEVICE;
   return stage_perm_zs(c, (const u64 *)betas, (const u64 *)gammas, (u64 *)cap);
 }
-extern "C" int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs, uint64_t *cap) {
-  if (!c || !alphas || !cap || (c->npi && !public_inputs)) return LCP2_E_INVALID;
+extern "C" int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4], uint64_t *cap) {
+  if (!c || !alphas || !cap || !public_inputs_hash) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  return stage_quotient(c, (const u64 *)alphas, (const u64 *)public_inputs, (u64 *)cap);
+  return stage_quotient(c, (const u64 *)alphas, (const u64 *)public_inputs_hash, (u64 *)cap);
 }
-extern "C" int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs) {
-  if (!c || !alphas || (c->npi && !public_inputs)) return LCP2_E_INVALID;
+extern "C" int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4]) {
+  if (!c || !alphas || !public_inputs_hash) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  return stage_quotient_values(c, (const u64 *)alphas, (const u64 *)public_inputs);
+  return stage_quotient_values(c, (const u64 *)alphas, (const u64 *)public_inputs_hash);
 }
 extern "C" int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words) {
   if (!c || !device_ptr || !words) return LCP2_E_INVALID;
@@ -756,7 +886,7 @@ extern "C" int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap) {
 // host-side transcript helpers (plonky2 Challenger / PoseidonHash::hash_no_pad) for callers without their own
 extern "C" void lcp2_challenger_init(lcp2_challenger *ch) { if (ch) memset(ch, 0, sizeof *ch); }
 extern "C" int lcp2_challenger_observe(lcp2_challenger *chs, const uint64_t *values, size_t count) {
-  if (!chs || (count && !values) || chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  if (!chs || (count && !values) || chs->input_len >= 8 || chs->output_len > 8) return LCP2_E_INVALID;  // 8 buffered inputs duplex at once: never stored
   HostChallenger ch;
   ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
   ch.observe_n((const u64 *)values, count);
@@ -764,7 +894,7 @@ extern "C" int lcp2_challenger_observe(lcp2_challenger *chs, const uint64_t *val
   return LCP2_OK;
 }
 extern "C" int lcp2_challenger_get(lcp2_challenger *chs, uint64_t *out, size_t count) {
-  if (!chs || (count && !out) || chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  if (!chs || (count && !out) || chs->input_len >= 8 || chs->output_len > 8) return LCP2_E_INVALID;
   HostChallenger ch;
   ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
   for (size_t i = 0; i < count; i++) out[i] = ch.get();
@@ -784,7 +914,7 @@ extern "C" int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t o
 extern "C" int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *chs, uint64_t *proof) {
   if (!c || !zeta || !chs || !proof) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  if (chs->input_len > 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  if (chs->input_len >= 8 || chs->output_len > 8) return LCP2_E_INVALID;
   HostChallenger ch;
   ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
   gl2 alpha, fri_betas[LCP2_MAX_FRI_LAYERS];

@@ -1,6 +1,7 @@
 // Argument blocks and launch wrappers of the prover kernels (kernels_prover.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "gl64.hpp"
 #include "ntt.hpp"
 
@@ -9,10 +10,18 @@ namespace lcp2 {
 constexpr u32 PERM_MAX_CHUNKS = 10;   // ceil(80 routed wires / quotient degree factor 8)
 constexpr u32 QUOTIENT_THREADS = 128;
 constexpr u32 QUOTIENT_MAX_CH = 2;
+// Operand staging of the gate-program interpreter (device-side form of the programs, made by stage_gate_programs at build()):
+// every WIRE / CONST operand is fetched by an LDG instruction that issues up to QUOTIENT_STAGE column loads back to back and
+// parks the values in LDS slots; the instructions after it read kind STAGE.  One exposed HBM round trip per 16 operands
+// instead of one per operand (the interpreter executes one instruction at a time, so an operand load cannot overlap anything).
+constexpr u32 QUOTIENT_STAGE = 12;
+constexpr u32 QUOTIENT_ALPHA_POWS = 32; // >= CH + CH * PERM_MAX_CHUNKS + 1 exponents
+constexpr u32 QOP_LDG = 10;      // w0 = 10 | count << 8, w1 = offset into stage_list
+constexpr u32 QKIND_STAGE = 5;   // operand = staging slot idx
 constexpr u32 EVAL_CHUNK = 4096;
 
 struct GateDev {  // = lcp2_gate
-  u32 selector_index, selector_value, group_start, group_end, code_offset, code_len, num_constraints;
+  u32 selector_index, selector_value, group_start, group_end, code_offset, code_len, num_constraints, flags;
 };
 
 struct PermArgs {
@@ -35,7 +44,15 @@ struct QuotientArgs {
   const u64 *l0;      // L_0 on the LDE points, leaf order [N]
   const u64 *zh_inv;  // 1 / Z_H per top-bits block of the leaf index, [2^rate_bits]
   TwoLevelTable points;  // 7 * w_N^j
-  const u64 *k_is, *betas, *gammas, *alphas, *pis, *imm;
+  const u64 *k_is, *betas, *gammas, *alphas, *pis, *imm;  // pis: public_inputs_hash[4]
+  // forward-emitting gates (LCP2_GATE_EMIT_FORWARD): sum_i alpha^i c_i = alpha^(m-1) * Horner(c_0 .. c_{m-1}; 1/alpha)
+  const u32 *stage_list;   // LDG column lists: entry < num_wires: wire column, else constants column (entry - num_wires)
+  u32 num_wires;
+  u32 use_native;          // 1: gates flagged LCP2_GATE_NATIVE_* run their native evaluator, 0: everything is interpreted
+  const u64 *rc;           // Poseidon round constants (native PoseidonGate evaluator)
+  const u64 *alpha_pow;    // [QUOTIENT_MAX_CH][QUOTIENT_ALPHA_POWS] alpha_c^e: weights of the permutation-term blocks
+  const u64 *alpha_inv;    // [CH], 0 where alpha = 0
+  const u64 *gate_scale;   // [num_gates][QUOTIENT_MAX_CH] alpha^(num_constraints - 1)
   const u32 *code;
   const GateDev *gates;
   u64 *out;           // [CH][N] quotient values, leaf order (always the full domain)
@@ -83,6 +100,16 @@ u64 scan_scratch_words(u64 n, u32 batches);
 void launch_perm_chunks(hipStream_t s, const PermArgs &a);
 void launch_perm_finalize(hipStream_t s, const PermArgs &a);
 void launch_quotient(hipStream_t s, const QuotientArgs &a);
+// host: rewrites validated gate programs into the staged device form (new code, per-gate offsets in `gates`, column lists)
+void stage_gate_programs(const std::vector<uint32_t> &code, std::vector<GateDev> &gates, u32 num_wires, u32 num_selectors,
+                         std::vector<uint32_t> &staged_code, std::vector<uint32_t> &stage_list);
+// Row-wise check of the gate constraints over the n rows of H (the Err of prove() for an unsatisfiable witness): the same
+// gate programs on the witness VALUES (a.wires = witness [W][n], a.consts = constants values [NC][n], a.stride = a.count = n);
+// *flag (device, zeroed by the caller) receives 1 + the smallest row with a non-zero filtered constraint combination.
+void launch_gate_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag);
+// build()-time check of the LCP2_GATE_NATIVE_* claims: on a.count random points (a.wires / a.consts hold random field
+// elements) the native evaluators and the interpreted programs must give the same combination; *flag as in launch_gate_check
+void launch_native_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag);
 void launch_eval_polys(hipStream_t s, const EvalArgs &a, u32 npolys, u64 *out);
 void launch_compose(hipStream_t s, const ComposeArgs &a);
 void launch_divide_finalize(hipStream_t s, const ComposeArgs &a, u64 *out0, u64 *out1);

@@ -17,13 +17,17 @@ inline gl2 rd2(const u64 *p) { return gl2_make(p[0], p[1]); }
 inline gl2 base2(u64 x) { return gl2_make(x, 0); }
 
 // gate programs over the extension field (evaluation at zeta)
+inline gl2 sbox7_ext(gl2 x) { gl2 x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2), x3 = gl2_mul(x2, x); return gl2_mul(x3, x4); }
 void eval_gates_ext(const VerifierView &v, const gl2 *wires, const gl2 *consts, const u64 *pis, const u64 *alphas, gl2 *out) {
+  static const u64 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   const u32 CH = v.p->num_challenges;
   for (u32 k = 0; k < CH; k++) out[k] = base2(0);
   gl2 regs[64];
   for (u32 g = 0; g < v.num_gates; g++) {
     const lcp2_gate &G = v.gates[g];
+    const bool fwd = (G.flags & LCP2_GATE_EMIT_FORWARD) != 0;
     gl2 acc[4] = {base2(0), base2(0), base2(0), base2(0)};
+    u64 apow[4] = {1, 1, 1, 1};  // forward gates: running powers of alpha (the prover kernel uses the 1 / alpha Horner form)
     for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
       const u32 w0 = v.code[2 * pc], w1 = v.code[2 * pc + 1];
       const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
@@ -36,12 +40,27 @@ void eval_gates_ext(const VerifierView &v, const gl2 *wires, const gl2 *consts, 
           default: return base2(pis[i]);
         }
       };
+      if (op == LCP2_OP_PMDS) {
+        gl2 in[12];
+        for (int i = 0; i < 12; i++) in[i] = regs[ia + i];
+        for (int r = 0; r < 12; r++) {
+          gl2 t = base2(v.imm[ib + r]);
+          if (r == 0) t = gl2_add(t, gl2_scale(in[0], 8));
+          for (int i = 0; i < 12; i++) t = gl2_add(t, gl2_scale(in[(i + r) % 12], CIRC[i]));
+          regs[dst + r] = t;
+        }
+        continue;
+      }
       gl2 a = fetch(ka, ia);
       if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
         if (op == LCP2_OP_EMITBOOL) a = gl2_sub(gl2_mul(a, a), a);
-        for (u32 k = 0; k < CH; k++) acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
+        for (u32 k = 0; k < CH; k++) {
+          if (fwd) { acc[k] = gl2_add(acc[k], gl2_scale(a, apow[k])); apow[k] = gl_mul(apow[k], alphas[k]); }
+          else acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
+        }
         continue;
       }
+      if (op == LCP2_OP_SBOX) { regs[dst] = sbox7_ext(a); continue; }
       gl2 b = fetch(kb, ib);
       switch (op) {
         case LCP2_OP_ADD: regs[dst] = gl2_add(a, b); break;
@@ -147,7 +166,7 @@ int verify_impl(const VerifierView &v, const u64 *proof, const u64 *pis_in) {
       }
     }
     gl2 gates[4];
-    eval_gates_ext(v, ow.data(), oc.data(), pis.data(), alphas, gates);
+    eval_gates_ext(v, ow.data(), oc.data(), pi_hash, alphas, gates);
     for (u32 k = 0; k < CH; k++) {
       gl2 acc = gates[k];
       for (size_t t = terms.size(); t-- > 0;) acc = gl2_add(gl2_scale(acc, alphas[k]), terms[t]);
@@ -207,10 +226,13 @@ int verify_impl(const VerifierView &v, const u64 *proof, const u64 *pis_in) {
 }
 }  // namespace
 
-extern "C" int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, const uint64_t *public_inputs, int *failed_check) {
+extern "C" int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, size_t proof_words, const uint64_t *public_inputs,
+                           size_t num_public_inputs, int *failed_check) {
   if (!c || !proof) return LCP2_E_INVALID;
   VerifierView v = verifier_view(c);
   if (v.npi && !public_inputs) return LCP2_E_INVALID;
+  // an untrusted proof is only ever read through the layout of THIS circuit: refuse any other length up front
+  if (proof_words != ProofLayout(*v.p).total || num_public_inputs != v.npi) return LCP2_E_INVALID;
   int rc = verify_impl(v, (const u64 *)proof, (const u64 *)public_inputs);
   if (failed_check) *failed_check = rc;
   return rc == 0 ? LCP2_OK : LCP2_E_VERIFY;

@@ -131,12 +131,8 @@ void CircuitBuilder::connect(Target a, Target b) {
   uint32_t ra = impl_->d->find(a.id), rb = impl_->d->find(b.id);
   if (ra != rb) p[std::max(ra, rb)] = std::min(ra, rb);
 }
-void CircuitBuilder::register_public_input(Target t) {
-  uint32_t i = (uint32_t)impl_->d->public_inputs.size();
-  if (i >= impl_->d->config.num_routed_wires) throw std::runtime_error("too many public inputs for one PublicInputGate");
-  impl_->d->public_inputs.push_back(t.id);
-  impl_->bind(0, i, t.id);
-}
+// the inputs are bound at build(): hashed in-circuit, the digest connected to the PublicInputGate of row 0
+void CircuitBuilder::register_public_input(Target t) { impl_->d->public_inputs.push_back(t.id); }
 size_t CircuitBuilder::num_gates() const { return impl_->d->nrows; }
 void CircuitBuilder::print_gate_counts(int) const {
   std::map<uint32_t, size_t> counts;
@@ -214,11 +210,35 @@ std::unique_ptr<CircuitData> CircuitBuilder::build() {
   std::unique_ptr<CircuitData> data(new CircuitData());
   CircuitData::Impl *d = b->d.get();
   const CircuitConfig &cfg = d->config;
+  {
+    // circuit_builder.rs::build: public_inputs_hash = hash_n_to_hash_no_pad::<PoseidonHash>(public_inputs) in-circuit (an
+    // overwrite-mode sponge of rate 8 over PoseidonGate rows, starting from the zero state, swap = false), connected to
+    // the wires of the PublicInputGate, which the gate compares with the hash the transcript uses
+    const uint32_t zero_var = zero().id;
+    std::array<uint32_t, 12> state;
+    state.fill(zero_var);
+    const size_t npi_ = d->public_inputs.size();
+    for (size_t off = 0; off < npi_; off += 8) {
+      const uint32_t row = b->new_row(G_POSEIDON);
+      Op op; op.kind = Op::POSEIDON; op.first_row = row;
+      for (uint32_t i = 0; i < 12; i++) {
+        op.in[i] = (i < 8 && off + i < npi_) ? d->public_inputs[off + i] : state[i];
+        const uint32_t out = b->new_var();
+        op.internal.push_back(out);
+        b->bind(row, POS_WIRE_INPUT + i, op.in[i]);
+        b->bind(row, POS_WIRE_OUTPUT + i, out);
+      }
+      b->bind(row, POS_WIRE_SWAP, zero_var);
+      for (uint32_t i = 0; i < 12; i++) state[i] = op.internal[i];
+      d->ops.push_back(op);
+    }
+    for (uint32_t i = 0; i < 4; i++) b->bind(0, i, state[i]);
+  }
   uint32_t degree_bits = 5;  // room for the cap-height-4 Merkle trees of every FRI layer
   while ((1u << degree_bits) < d->nrows) degree_bits++;
   const uint64_t n = 1ull << degree_bits;
   const uint32_t NR = cfg.num_routed_wires, npi = (uint32_t)d->public_inputs.size();
-  GateSetLayout gs = build_gate_set(npi, cfg.max_quotient_degree_factor + 1);
+  GateSetLayout gs = build_gate_set(cfg.max_quotient_degree_factor + 1);
   CircuitDescription &D = data->desc_;
   if (lcp2_params_standard(degree_bits, gs.num_selectors + cfg.num_constants, &D.params) != LCP2_OK) throw std::runtime_error("bad circuit size");
   D.params.num_wires = cfg.num_wires; D.params.num_routed_wires = NR; D.params.rate_bits = cfg.rate_bits; D.params.cap_height = cfg.cap_height;
@@ -375,6 +395,16 @@ void eval_sha(const Op &op, Values &V, std::vector<uint64_t> &wires, uint64_t n)
 }
 }  // namespace
 
+// PoseidonGenerator: the 12 outputs and every internal wire of the row (S-box inputs, deltas); `raw` collects the cells
+// of the row that are not bound to a target
+static void eval_poseidon(const Op &op, Values &V, std::vector<lcp2_cell> &raw) {
+  F in[12], row[POS_GATE_WIRES];
+  for (int i = 0; i < 12; i++) in[i] = V.get(op.in[i], "poseidon input");
+  poseidon_gate_row(in, false, row);
+  for (int i = 0; i < 12; i++) V.set(op.internal[i], row[POS_WIRE_OUTPUT + i], "poseidon output");
+  for (uint32_t c = POS_WIRE_DELTA; c < POS_GATE_WIRES; c++) raw.push_back(lcp2_cell{op.first_row, c, row[c]});
+}
+
 // split_le generator: the low c0 bits of x; a value that does not fit cannot satisfy the recomposition constraint
 static void eval_bits(const Op &op, Values &V) {
   const F x = V.get(op.x, "split_le input");
@@ -396,8 +426,10 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
     if (op.kind == Op::ARITH) return has(op.x) && has(op.y) && has(op.z);
     if (op.kind == Op::BITS) return has(op.x);
     if (op.kind == Op::SHA) { for (uint32_t v : op.in) if (!has(v)) return false; }
+    if (op.kind == Op::POSEIDON) { for (int i = 0; i < 12; i++) if (!has(op.in[i])) return false; }
     return true;
   };
+  std::vector<lcp2_cell> raw;
   std::vector<const Op *> pending;
   for (const Op &op : d->ops) pending.push_back(&op);
   while (!pending.empty()) {
@@ -414,11 +446,13 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
         }
         case Op::SHA: eval_sha(op, V, wires, n); break;
         case Op::BITS: eval_bits(op, V); break;
+        case Op::POSEIDON: eval_poseidon(op, V, raw); break;
       }
     }
     if (waiting.size() == pending.size()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
     pending.swap(waiting);
   }
+  for (const lcp2_cell &c : raw) wires[(size_t)c.col * n + c.row] = c.value;
   for (const CellBinding &c : d->cells) wires[(size_t)c.col * n + c.row] = V.get(c.var, "wire cell");
   public_inputs.clear();
   for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
@@ -456,6 +490,7 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   std::vector<const Op *> host_ops, sha_ops;
   for (const Op &op : d->ops) (op.kind == Op::SHA ? sha_ops : host_ops).push_back(&op);
   auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
+  std::vector<lcp2_cell> cells;  // everything the host writes: unbound cells of PoseidonGate rows, then the bound cells
   while (true) {
     bool progress = true;
     while (progress && !host_ops.empty()) {  // host worklist
@@ -464,7 +499,13 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       for (const Op *op : host_ops) {
         if (op->kind == Op::ARITH && !(has(op->x) && has(op->y) && has(op->z))) { waiting.push_back(op); continue; }
         if (op->kind == Op::BITS && !has(op->x)) { waiting.push_back(op); continue; }
-        if (op->kind == Op::CONST) V.set(op->out, op->c0, "constant");
+        if (op->kind == Op::POSEIDON) {
+          bool ok = true;
+          for (int i = 0; i < 12; i++) ok = ok && has(op->in[i]);
+          if (!ok) { waiting.push_back(op); continue; }
+          eval_poseidon(*op, V, cells);
+        }
+        else if (op->kind == Op::CONST) V.set(op->out, op->c0, "constant");
         else if (op->kind == Op::BITS) eval_bits(*op, V);
         else V.set(op->out, f_add(f_mul(f_mul(V.get(op->x, "x"), V.get(op->y, "y")), op->c0), f_mul(V.get(op->z, "z"), op->c1)), "arithmetic output");
         progress = true;
@@ -525,7 +566,6 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   }
   if (!host_ops.empty()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
   // the cells of the non-SHA rows
-  std::vector<lcp2_cell> cells;
   for (const CellBinding &c : d->cells) {
     uint32_t g = d->gate_of_row[c.row];
     if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED) continue;
@@ -549,7 +589,10 @@ ProofWithPublicInputs CircuitData::prove(const PartialWitness &pw) {
   ProofWithPublicInputs out;
   generate_witness_gpu(pw, out.public_inputs);  // throws UnsatisfiedError = plonky2's Err; the witness stays in HBM
   out.proof.assign(lcp2_proof_words(&desc_.params), 0);
-  int rc = lcp2_prove(impl_->gpu, (const uint64_t *)impl_->d_wires, LCP2_MEM_DEVICE, out.public_inputs.data(), out.proof.data());
+  int rc = lcp2_prove(impl_->gpu, (const uint64_t *)impl_->d_wires, LCP2_MEM_DEVICE, out.public_inputs.data(), out.public_inputs.size(),
+                      out.proof.data(), out.proof.size());
+  // the generators above already reject an inconsistent witness; LCP2_E_UNSAT is the device-side check saying the same
+  if (rc == LCP2_E_UNSAT) throw UnsatisfiedError(std::string("lcp2_prove: ") + lcp2_last_error(impl_->ctx));
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_prove: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(impl_->ctx) + ")");
   return out;
 }
@@ -558,7 +601,7 @@ void CircuitData::verify(const ProofWithPublicInputs &proof) const {
   const lcp2_circuit *c = impl_->gpu ? impl_->gpu : impl_->verifier;
   if (!c) throw std::runtime_error("CircuitData::verify needs the circuit digest: attach_gpu() first");
   int failed = 0;
-  int rc = lcp2_verify(c, proof.proof.data(), proof.public_inputs.data(), &failed);
+  int rc = lcp2_verify(c, proof.proof.data(), proof.proof.size(), proof.public_inputs.data(), proof.public_inputs.size(), &failed);
   if (rc == LCP2_E_VERIFY) throw VerifyError("proof rejected (check " + std::to_string(failed) + ")");
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_verify: ") + lcp2_status_str(rc));
 }

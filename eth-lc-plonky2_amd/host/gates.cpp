@@ -16,14 +16,14 @@ namespace lc {
 
 const char *gate_name(uint32_t k) {
   static const char *names[G_COUNT] = {"NoopGate", "ConstantGate", "PublicInputGate", "ShaAddGate", "ArithmeticGate",
-                                       "ShaRoundAGate", "ShaRoundEGate", "ShaScheduleGate"};
+                                       "ShaRoundAGate", "ShaRoundEGate", "ShaScheduleGate", "PoseidonGate"};
   return k < G_COUNT ? names[k] : "?";
 }
-const uint32_t GATE_DEGREE[G_COUNT] = {0, 1, 1, 2, 3, 3, 3, 3};
+const uint32_t GATE_DEGREE[G_COUNT] = {0, 1, 1, 2, 3, 3, 3, 3, 7};
 
 namespace {
 enum { OP_ADD = LCP2_OP_ADD, OP_SUB = LCP2_OP_SUB, OP_MUL = LCP2_OP_MUL, OP_EMIT = LCP2_OP_EMIT, OP_XOR = LCP2_OP_XOR, OP_DBLADD = LCP2_OP_DBLADD,
-       OP_EMITBOOL = LCP2_OP_EMITBOOL, OP_MULADD = LCP2_OP_MULADD };
+       OP_EMITBOOL = LCP2_OP_EMITBOOL, OP_MULADD = LCP2_OP_MULADD, OP_SBOX = LCP2_OP_SBOX, OP_PMDS = LCP2_OP_PMDS };
 enum { K_REG = 0, K_WIRE = 1, K_CONST = 2, K_IMM = 3, K_PI = 4 };
 struct Opnd { uint32_t kind, idx; };
 inline Opnd R(uint32_t i) { return {K_REG, i}; }
@@ -34,8 +34,9 @@ inline Opnd PI(uint32_t i) { return {K_PI, i}; }
 struct Asm {
   std::vector<uint32_t> &code;
   std::vector<uint64_t> &imm;
-  uint32_t max_reg = 0, nconstraints = 0;
-  // constraints are collected per index and written out last-to-first (EMIT is a Horner step)
+  uint32_t max_reg = 0, nconstraints = 0, flags = 0;
+  // constraints are collected per index and written out last-to-first (EMIT is a Horner step); a gate that sets
+  // LCP2_GATE_EMIT_FORWARD writes its blocks in order instead
   std::vector<std::vector<uint32_t>> blocks;
   std::vector<uint32_t> *cur = nullptr;
   Asm(std::vector<uint32_t> &c, std::vector<uint64_t> &i) : code(c), imm(i) {}
@@ -58,7 +59,17 @@ struct Asm {
   void muladd(uint32_t d, Opnd a, Opnd b) { op(OP_MULADD, d, a, b); }   // r[d] += a * b
   void emit(Opnd a) { cur->push_back(OP_EMIT | a.kind << 16); cur->push_back(a.idx); nconstraints++; }
   void emit_bool(Opnd a) { cur->push_back(OP_EMITBOOL | a.kind << 16); cur->push_back(a.idx); nconstraints++; }
+  void sbox(uint32_t d, Opnd a) { op(OP_SBOX, d, a, R(0)); }             // r[d] = a^7
+  // r[d .. d+12) = MDS * r[src .. src+12) + the 12 constants (a contiguous block of immediates)
+  void pmds(uint32_t d, uint32_t src, const uint64_t constants[12]) {
+    const uint32_t base = (uint32_t)imm.size();
+    imm.insert(imm.end(), constants, constants + 12);
+    if (d + 12 > max_reg) max_reg = d + 12;
+    cur->push_back(OP_PMDS | d << 8 | K_REG << 16 | K_IMM << 20);
+    cur->push_back(src | base << 16);
+  }
   void finish() {
+    if (flags & LCP2_GATE_EMIT_FORWARD) { for (auto &b : blocks) code.insert(code.end(), b.begin(), b.end()); return; }
     for (size_t k = blocks.size(); k-- > 0;) code.insert(code.end(), blocks[k].begin(), blocks[k].end());
   }
   // ---- constraint helpers (each is one constraint block)
@@ -80,11 +91,12 @@ struct Asm {
 constexpr uint64_t TWO32 = 1ull << 32;
 
 void prog_noop(Asm &) {}
+// plonky2's own gates, constraint for constraint (gates/constant.rs, public_input.rs, arithmetic_base.rs, poseidon.rs [RECALL])
 void prog_constant(Asm &a) {
-  for (int i = 0; i < 2; i++) { a.begin(); a.sub(0, W(i), C(i)); a.emit(R(0)); }
+  for (int i = 0; i < 2; i++) { a.begin(); a.sub(0, C(i), W(i)); a.emit(R(0)); }
 }
-void prog_public_input(Asm &a, uint32_t npi) {
-  for (uint32_t i = 0; i < npi; i++) { a.begin(); a.sub(0, W(i), PI(i)); a.emit(R(0)); }
+void prog_public_input(Asm &a) {  // wires 0..4 against public_inputs_hash
+  for (uint32_t i = 0; i < 4; i++) { a.begin(); a.sub(0, W(i), PI(i)); a.emit(R(0)); }
 }
 void prog_arithmetic(Asm &a) {
   for (int k = 0; k < 20; k++) {
@@ -93,9 +105,61 @@ void prog_arithmetic(Asm &a) {
     a.mul(0, R(0), C(0));
     a.mul(1, W(4 * k + 2), C(1));
     a.add(0, R(0), R(1));
-    a.sub(0, R(0), W(4 * k + 3));
+    a.sub(0, W(4 * k + 3), R(0));
     a.emit(R(0));
   }
+}
+// PoseidonGate: 123 constraints in the order of eval_unfiltered, emitted first to last (one forward pass over the rounds):
+// swap booleanity, 4 delta equations, `state - sbox_in` for every S-box that has a wire, the 12 outputs.  The partial rounds
+// are in the naive form; plonky2's fast-partial-round form is the same polynomial in the wires.
+void prog_poseidon(Asm &a) {
+  const uint64_t *rc = poseidon_round_constants();
+  const uint64_t zeros[12] = {0};
+  a.flags |= LCP2_GATE_EMIT_FORWARD | LCP2_GATE_NATIVE_POSEIDON;  // the library checks the native claim at build()
+  const uint32_t T = 12;  // scratch register; r0..r11 hold the state
+  a.begin(); a.emit_bool(W(POS_WIRE_SWAP));
+  for (uint32_t i = 0; i < 4; i++) {
+    a.begin();
+    a.sub(T, W(POS_WIRE_INPUT + i + 4), W(POS_WIRE_INPUT + i));
+    a.mul(T, R(T), W(POS_WIRE_SWAP));
+    a.sub(T, R(T), W(POS_WIRE_DELTA + i));
+    a.emit(R(T));
+  }
+  a.begin();
+  for (uint32_t i = 0; i < 4; i++) {
+    a.add(i, W(POS_WIRE_INPUT + i), W(POS_WIRE_DELTA + i));
+    a.add(i, R(i), a.IMM(rc[i]));
+    a.sub(i + 4, W(POS_WIRE_INPUT + i + 4), W(POS_WIRE_DELTA + i));
+    a.add(i + 4, R(i + 4), a.IMM(rc[i + 4]));
+  }
+  for (uint32_t i = 8; i < 12; i++) a.add(i, W(POS_WIRE_INPUT + i), a.IMM(rc[i]));
+  uint32_t rnd = 0;
+  auto next = [&]() { return rnd + 1 < 30 ? rc + 12 * (rnd + 1) : zeros; };
+  for (uint32_t r = 0; r < 4; r++, rnd++) {
+    for (uint32_t i = 0; i < 12; i++) {
+      if (r) {
+        const Opnd w = W(pos_wire_full_sbox_0(r, i));
+        a.sub(T, R(i), w); a.emit(R(T)); a.begin();
+        a.sbox(i, w);
+      } else a.sbox(i, R(i));
+    }
+    a.pmds(0, 0, next());
+  }
+  for (uint32_t r = 0; r < 22; r++, rnd++) {
+    const Opnd w = W(POS_WIRE_PARTIAL + r);
+    a.sub(T, R(0), w); a.emit(R(T)); a.begin();
+    a.sbox(0, w);
+    a.pmds(0, 0, next());
+  }
+  for (uint32_t r = 0; r < 4; r++, rnd++) {
+    for (uint32_t i = 0; i < 12; i++) {
+      const Opnd w = W(pos_wire_full_sbox_1(r, i));
+      a.sub(T, R(i), w); a.emit(R(T)); a.begin();
+      a.sbox(i, w);
+    }
+    a.pmds(0, 0, next());
+  }
+  for (uint32_t i = 0; i < 12; i++) { a.sub(T, R(i), W(POS_WIRE_OUTPUT + i)); a.emit(R(T)); a.begin(); }
 }
 void prog_sha_add(Asm &a) {
   for (int j = 0; j < SHA_ADD_OPS; j++) {
@@ -184,7 +248,7 @@ void prog_sha_sched(Asm &a) {
 }  // namespace
 
 // selector groups: plonky2 gates/selectors.rs greedy grouping with max_degree = quotient_degree_factor + 1
-GateSetLayout build_gate_set(uint32_t npi, uint32_t max_degree) {
+GateSetLayout build_gate_set(uint32_t max_degree) {
   GateSetLayout gs;
   uint32_t n = G_COUNT;
   std::vector<std::pair<uint32_t, uint32_t>> groups;
@@ -208,17 +272,18 @@ GateSetLayout build_gate_set(uint32_t npi, uint32_t max_degree) {
     switch (g) {
       case G_NOOP: prog_noop(a); break;
       case G_CONSTANT: prog_constant(a); break;
-      case G_PUBLIC_INPUT: prog_public_input(a, npi); break;
+      case G_PUBLIC_INPUT: prog_public_input(a); break;
       case G_SHA_ADD: prog_sha_add(a); break;
       case G_ARITHMETIC: prog_arithmetic(a); break;
       case G_SHA_ROUND_A: prog_sha_round_a(a); break;
       case G_SHA_ROUND_E: prog_sha_round_e(a); break;
       case G_SHA_SCHED: prog_sha_sched(a); break;
+      case G_POSEIDON: prog_poseidon(a); break;
     }
     a.finish();
     uint32_t sel = 0;
     for (uint32_t s = 0; s < groups.size(); s++) if (groups[s].first <= g && g < groups[s].second) sel = s;
-    lcp2_gate G{sel, g, groups[sel].first, groups[sel].second, off, (uint32_t)gs.code.size() / 2 - off, a.nconstraints};
+    lcp2_gate G{sel, g, groups[sel].first, groups[sel].second, off, (uint32_t)gs.code.size() / 2 - off, a.nconstraints, a.flags};
     gs.gates.push_back(G);
     if (a.max_reg > gs.num_regs) gs.num_regs = a.max_reg;
   }

@@ -17,7 +17,15 @@ struct GateSetLayout {
   std::vector<uint32_t> code;
   std::vector<uint64_t> imm;
 };
-GateSetLayout build_gate_set(uint32_t num_public_inputs, uint32_t max_degree);
+GateSetLayout build_gate_set(uint32_t max_degree);
+
+// PoseidonGate wire layout (plonky2 gates/poseidon.rs) and the host-side permutation that fills a row (poseidon_host.cpp)
+constexpr uint32_t POS_WIRE_INPUT = 0, POS_WIRE_OUTPUT = 12, POS_WIRE_SWAP = 24, POS_WIRE_DELTA = 25, POS_WIRE_FULL_0 = 29,
+                   POS_WIRE_PARTIAL = 65, POS_WIRE_FULL_1 = 87, POS_GATE_WIRES = 135;
+inline uint32_t pos_wire_full_sbox_0(uint32_t round, uint32_t i) { return POS_WIRE_FULL_0 + 12 * (round - 1) + i; }  // rounds 1..3
+inline uint32_t pos_wire_full_sbox_1(uint32_t round, uint32_t i) { return POS_WIRE_FULL_1 + 12 * round + i; }
+const uint64_t *poseidon_round_constants();                    // 360 values
+void poseidon_gate_row(const F in[12], bool swap, F row[135]); // PoseidonGenerator::run_once: every wire of one row
 extern const uint32_t GATE_DEGREE[G_COUNT];
 
 // ---- Goldilocks on the host (circuit construction / witness generation only)
@@ -31,7 +39,8 @@ extern const uint32_t SHA_IV[8];
 
 // one generator step, evaluated in creation order by generate_witness
 struct Op {
-  enum Kind { CONST, ARITH, SHA, BITS } kind;  // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
+  enum Kind { CONST, ARITH, SHA, BITS, POSEIDON } kind;  // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
+                                                         // POSEIDON: in[0..12) -> internal[0..12) on row first_row (swap = 0)
   uint32_t out = 0, x = 0, y = 0, z = 0;  // CONST: out ; ARITH: x, y, z -> out
   F c0 = 0, c1 = 0;                        // CONST: c0 = value
   // SHA: message words in[16] -> digest out8[8]; internal words by row

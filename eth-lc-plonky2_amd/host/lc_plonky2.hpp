@@ -8,7 +8,8 @@
 //   PartialWitness::{set_target, set_target_arr}, CircuitData::{prove, verify}       (src/main.rs:226-233)
 //   the gadgets of src/merkle_tree_gadget.rs, src/sync_committee_pubkeys.rs and src/targets.rs (gadgets.hpp)
 // Differences that the C ABI forces are documented in DESIGN.md: gates are gate programs, the SHA-256 gate
-// layout is this repository's own (plonky2_crypto's is not visible), public inputs are bound directly.
+// layout is this repository's own (plonky2_crypto's is not visible).  Public inputs are bound as plonky2 binds them:
+// build() hashes them in-circuit with PoseidonGate rows and connects the digest to the PublicInputGate.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -40,7 +41,7 @@ struct CircuitConfig {
 };
 
 // gate kinds of the own layout (sorted by degree then name, as plonky2 sorts its gate set)
-enum GateKind : uint32_t { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_SHA_ADD, G_ARITHMETIC, G_SHA_ROUND_A, G_SHA_ROUND_E, G_SHA_SCHED, G_COUNT };
+enum GateKind : uint32_t { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_SHA_ADD, G_ARITHMETIC, G_SHA_ROUND_A, G_SHA_ROUND_E, G_SHA_SCHED, G_POSEIDON, G_COUNT };
 const char *gate_name(uint32_t kind);
 
 class PartialWitness {

@@ -129,7 +129,8 @@ class ShardedProver:
         pis = np.asarray(public_inputs, dtype=np.uint64)
         ch = b.Challenger()
         ch.observe(self.digest)
-        ch.observe(b.hash_no_pad(pis))
+        pi_hash = b.hash_no_pad(pis)
+        ch.observe(pi_hash)
         share = d.commit_wires(wires, mem)
         proof[0:capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[0:capw])
@@ -138,7 +139,7 @@ class ShardedProver:
         proof[capw:2 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[capw:2 * capw])
         alphas = ch.get(p.num_challenges)
-        d.quotient_values(alphas, pis)
+        d.quotient_values(alphas, pi_hash)
         yield ("sum_device",) + d.quotient_buffer()
         share = d.quotient_commit()
         proof[2 * capw:3 * capw] = (yield ("sum_host", share)).ravel()

@@ -14,8 +14,10 @@
  *
  * Conventions
  *  - return 0 (LCP2_OK) or a negative lcp2_status; nothing throws or aborts
- *    across the ABI.  An unsatisfiable witness gives LCP2_E_UNSAT, mirroring
- *    the `Err` of `prove()` that the reference's #[should_panic] tests rely on.
+ *    across the ABI.  A witness that violates a gate constraint or a copy
+ *    constraint gives LCP2_E_UNSAT from lcp2_prove / lcp2_quotient (checked on the
+ *    device over the n rows of H before the quotient is formed), mirroring the
+ *    `Err` of `prove()` that the reference's #[should_panic] tests rely on.
  *  - field elements are little-endian uint64_t Goldilocks values; inputs may be
  *    non-canonical (any value < 2^64), outputs are canonical.
  *  - extension elements are two uint64_t [c0, c1] (X^2 = 7).
@@ -37,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LCP2_ABI_VERSION 1
+#define LCP2_ABI_VERSION 2
 
 typedef enum {
   LCP2_OK = 0,
@@ -189,20 +191,34 @@ int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs /* nullable */, uint64_t *
  * constraint program ("gate program") that the quotient kernel (K6) and the
  * verifier interpret:
  *     instruction = 2 words:  w0 = op | dst << 8 | kind_a << 16 | kind_b << 20,  w1 = idx_a | idx_b << 16
- *     op   0 ADD  1 SUB  2 MUL (dst <- a op b)   3 EMIT (acc <- acc * alpha + a)
+ *     op   0 ADD  1 SUB  2 MUL (dst <- a op b)   3 EMIT (the next constraint of the gate is a)
  *          4 XOR (dst <- a + b - 2ab)  5 DBLADD (dst <- 2a + b)  6 EMITBOOL (EMIT of a*a - a)  7 MULADD (dst <- dst + a*b)
+ *          8 SBOX (dst <- a^7, the Poseidon S-box)
+ *          9 PMDS (Poseidon MDS layer on a window of 12 registers, with the constants that follow it:
+ *                  reg[dst + r] <- sum_i reg[idx_a + (i + r) % 12] * MDS_CIRC[i] + reg[idx_a + r] * MDS_DIAG[r] + imm[idx_b + r],
+ *                  r < 12; kind_a = REG, kind_b = IMM; the two windows may be the same)
  *     kind 0 REG  1 WIRE (local wire)  2 CONST (gate constant, after the selector columns)
- *          3 IMM (imm[idx])  4 PI (public_inputs[idx])
- * A gate lists its constraints from the LAST to the FIRST (EMIT is a Horner step).
+ *          3 IMM (imm[idx])  4 PI (public_inputs_hash[idx], idx < 4: what plonky2's PublicInputGate compares its wires with)
+ * A gate's constraints c_0 .. c_{m-1} enter the quotient as sum_i alpha^i c_i.  By default a program lists them from the
+ * LAST to the FIRST (EMIT is then a Horner step acc <- acc * alpha + a); with LCP2_GATE_EMIT_FORWARD in `flags` it lists
+ * them from the first to the last (gates such as PoseidonGate whose constraints fall out of one forward pass).
  * Selectors follow plonky2 gates/selectors.rs: gate g is active on rows where
  * constants[selector_index] == selector_value; its filter is
  *     prod_{j in [group_start, group_end), j != selector_value} (j - s) * (num_selectors > 1 ? (2^32 - 1 - s) : 1). */
 enum { LCP2_OP_ADD = 0, LCP2_OP_SUB = 1, LCP2_OP_MUL = 2, LCP2_OP_EMIT = 3, LCP2_OP_XOR = 4, LCP2_OP_DBLADD = 5,
-       LCP2_OP_EMITBOOL = 6, LCP2_OP_MULADD = 7 };
+       LCP2_OP_EMITBOOL = 6, LCP2_OP_MULADD = 7, LCP2_OP_SBOX = 8, LCP2_OP_PMDS = 9 };
+#define LCP2_GATE_EMIT_FORWARD 1u
+/* Bits 8..15 of `flags`: the caller's claim that the program is one of plonky2's gates in its standard wire layout, for which
+ * the library has a native device evaluator (same constraints, no interpretation).  The claim is CHECKED at
+ * lcp2_circuit_create: program and native evaluator must agree on random wire values, otherwise LCP2_E_INVALID.  The
+ * verifier always interprets the program.  0 = none. */
+#define LCP2_GATE_NATIVE_MASK 0xFF00u
+#define LCP2_GATE_NATIVE_POSEIDON 0x0100u /* PoseidonGate, gates/poseidon.rs: 135 wires, 123 constraints, EMIT_FORWARD order */
 typedef struct {
   uint32_t selector_index, selector_value, group_start, group_end;
   uint32_t code_offset, code_len; /* in instructions */
   uint32_t num_constraints;
+  uint32_t flags;                 /* LCP2_GATE_EMIT_FORWARD | LCP2_GATE_NATIVE_* */
 } lcp2_gate;
 
 typedef struct {
@@ -219,14 +235,15 @@ typedef struct {
   size_t code_words;
   const uint64_t *imm;             /* host */
   size_t num_imm;
-  uint32_t num_public_inputs;      /* bound by the PublicInput gate program through kind PI */
+  uint32_t num_public_inputs;      /* length of the public-input vector; the circuit binds it through its hash (kind PI) */
   uint32_t num_regs;               /* registers the programs use (<= 64) */
 } lcp2_circuit_desc;
 
 typedef struct lcp2_circuit lcp2_circuit; /* = CircuitData: prover_only + verifier_only + common */
 
 /* build(): uploads the description, commits constants_sigmas (PolynomialBatch::from_values),
- * derives the circuit digest and allocates the per-proof workspace in HBM. */
+ * derives the circuit digest = hash_no_pad(constants_sigmas_cap || hash_pad(domain separator = []) || degree_bits)
+ * (plonky2 circuit_builder.rs::build) and allocates the per-proof workspace in HBM. */
 int lcp2_circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, lcp2_circuit **out);
 void lcp2_circuit_destroy(lcp2_circuit *c);
 /* circuit_digest (4 elements) and constants_sigmas_cap (2^cap_height * 4), host buffers, cap nullable */
@@ -238,9 +255,12 @@ int lcp2_circuit_digest(const lcp2_circuit *c, uint64_t digest[4], uint64_t *cap
 size_t lcp2_proof_words(const lcp2_params *p);
 
 /* data.prove(pw): wires is the full witness (generate_partial_witness output), column-major
- * [num_wires][n]; public_inputs and proof are host buffers.  The proof-of-work witness is the
- * smallest valid one (plonky2 searches with a nondeterministic find_any). */
-int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const uint64_t *public_inputs, uint64_t *proof);
+ * [num_wires][n]; public_inputs (num_public_inputs elements, must equal the circuit's count) and proof
+ * (proof_words words, must equal lcp2_proof_words) are host buffers.  The proof-of-work witness is the
+ * smallest valid one (plonky2 searches with a nondeterministic find_any).  LCP2_E_UNSAT: the witness violates
+ * a gate or a copy constraint (nothing useful is in `proof`). */
+int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const uint64_t *public_inputs, size_t num_public_inputs,
+               uint64_t *proof, size_t proof_words);
 
 /* ---- the seams inside data.prove() a plonky2 fork binds one by one; lcp2_prove is exactly their
  * composition under the Fiat-Shamir transcript, and the caller keeps its own Challenger in between.  The commitments
@@ -249,10 +269,11 @@ int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const
  *   lcp2_perm_zs       wires_permutation_partial_products_and_zs + from_values    -> Z/partial-product cap (K5, K1-K4)
  *   lcp2_quotient      compute_quotient_polys + from_coeffs                       -> quotient cap          (K6, K1-K4)
  *   lcp2_fri_open      OpeningSet::new + PolynomialBatch::prove_openings           -> openings + FriProof   (K7-K9, a13)
- * betas/gammas/alphas: num_challenges base-field elements each; caps: 4 << cap_height words. */
+ * betas/gammas/alphas: num_challenges base-field elements each; caps: 4 << cap_height words;
+ * public_inputs_hash: the 4 elements of hash_no_pad(public inputs), as compute_quotient_polys takes it. */
 int lcp2_commit_wires(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, uint64_t *cap);
 int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap);
-int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs, uint64_t *cap);
+int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4], uint64_t *cap);
 /* plonky2's Challenger { sponge_state, input_buffer, output_buffer } (iop/challenger.rs), by value */
 typedef struct {
   uint64_t sponge[12];
@@ -288,14 +309,16 @@ int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* 
 int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, uint32_t block_first, uint32_t block_count,
                                 lcp2_circuit **out);
 int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap);
-int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t *public_inputs);
+int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4]);
 int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words);
 int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap);
 
-/* data.verify(proof): host only (no device work).  LCP2_OK or LCP2_E_VERIFY; *failed_check (nullable):
- * 1 encoding, 2 proof of work, 3 vanishing identity, 4 initial Merkle proof, 5 FRI consistency,
- * 6 FRI layer Merkle proof, 7 final polynomial. */
-int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, const uint64_t *public_inputs, int *failed_check);
+/* data.verify(proof): host only (no device work).  proof_words / num_public_inputs are the lengths of the two
+ * buffers: anything but lcp2_proof_words() / the circuit's public-input count is LCP2_E_INVALID (a truncated proof is
+ * never read).  LCP2_OK or LCP2_E_VERIFY; *failed_check (nullable): 1 encoding, 2 proof of work, 3 vanishing identity,
+ * 4 initial Merkle proof, 5 FRI consistency, 6 FRI layer Merkle proof, 7 final polynomial. */
+int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, size_t proof_words, const uint64_t *public_inputs,
+                size_t num_public_inputs, int *failed_check);
 
 /* Verifier-only circuit (VerifierCircuitData): no device, no context.  Takes the gate set, k_is and
  * parameters from `desc` (constants_sigmas is ignored and may be NULL) plus the circuit digest and the

@@ -17,8 +17,9 @@
  * prove -> verify plus tamper tests.  Deliberate deviations, both documented in
  * (1) the proof-of-work witness is the MINIMUM valid one (plonky2 uses a
  * nondeterministic rayon find_any); (2) gates are described by a small constraint
- * bytecode ("gate program") because the real gate set is not visible, and public
- * inputs are bound by a PublicInput gate that compares wires with the inputs directly.
+ * bytecode ("gate program") because plonky2's gate objects cannot cross a C ABI; the
+ * programs of plonky2's own gates (tests/ and eth-lc-plonky2_amd/circuit.py) restate their eval_unfiltered.
+ * Public inputs are bound as in plonky2: PublicInputGate compares four wires with public_inputs_hash.
  */
 #include "plonk.h"
 #include <stdio.h>
@@ -128,12 +129,16 @@ static orc_circuit *circuit_new(const orc_params *p, const uint64_t *constants_s
   for (uint32_t g = 0; g < num_gates; g++) if (gates[g].num_constraints > c->max_gate_constraints) c->max_gate_constraints = gates[g].num_constraints;
   if (!commit) return c; /* witness checking only: no preprocessed commitment, no digest */
   c->cs = batch_from_values(c->cs_values, ncs, p->degree_bits, p->rate_bits, p->cap_height);
-  /* circuit digest = H(constants_sigmas_cap || degree_bits) */
+  /* circuit_builder.rs::build: circuit_digest = hash_no_pad(constants_sigmas_cap || domain_separator_digest || degree_bits),
+   * domain_separator_digest = hash_pad(domain_separator), the separator empty by default: pad10*1 to one rate block
+   * [1, 0, 0, 0, 0, 0, 0, 1] */
   size_t capw = (size_t)4 << p->cap_height;
-  uint64_t *buf = (uint64_t *)xmalloc((capw + 1) * 8);
+  uint64_t *buf = (uint64_t *)xmalloc((capw + 5) * 8);
   memcpy(buf, c->cs->tree->cap, capw * 8);
-  buf[capw] = p->degree_bits;
-  orc_hash_no_pad(buf, capw + 1, c->digest);
+  const uint64_t empty_padded[8] = {1, 0, 0, 0, 0, 0, 0, 1};
+  orc_hash_no_pad(empty_padded, 8, buf + capw);
+  buf[capw + 4] = p->degree_bits;
+  orc_hash_no_pad(buf, capw + 5, c->digest);
   free(buf);
   return c;
 }
@@ -230,7 +235,13 @@ static uint64_t filter_b(const orc_circuit *c, const orc_gate *g, const uint64_t
   if (c->num_selectors > 1) f = gl_mul(f, gl_sub(ORC_UNUSED_SELECTOR, s));
   return f;
 }
-/* out[ch] = sum_gates filter * sum_i alpha_ch^i constraint_i ; raw (nullable): unfiltered constraints of gate `raw_gate` */
+static const uint64_t PMDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static const uint64_t PMDS_DIAG[12] = {8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static inline uint64_t sbox7_b(uint64_t x) { uint64_t x2 = gl_mul(x, x), x4 = gl_mul(x2, x2), x3 = gl_mul(x2, x); return gl_mul(x3, x4); }
+
+/* out[ch] = sum_gates filter * sum_i alpha_ch^i constraint_i ; raw (nullable): unfiltered constraints of gate `raw_gate`.
+ * The sum over a gate's constraints is accumulated with running powers of alpha for ORC_GATE_EMIT_FORWARD gates and as a
+ * Horner chain for the others (their programs list the constraints last to first): two formulations of the same sum. */
 static void eval_gates_base(const orc_circuit *c, const uint64_t *wires, const uint64_t *consts, const uint64_t *pis,
                             const uint64_t *alphas, uint64_t *out, int raw_gate, uint64_t *raw) {
   uint32_t CH = c->p.num_challenges;
@@ -238,18 +249,33 @@ static void eval_gates_base(const orc_circuit *c, const uint64_t *wires, const u
   uint64_t regs[ORC_MAX_REGS];
   for (uint32_t g = 0; g < c->num_gates; g++) {
     const orc_gate *G = &c->gates[g];
-    uint64_t acc[4] = {0, 0, 0, 0};
+    const int fwd = (G->flags & ORC_GATE_EMIT_FORWARD) != 0;
+    uint64_t acc[4] = {0, 0, 0, 0}, apow[4] = {1, 1, 1, 1};
     uint32_t emitted = 0;
     for (uint32_t pc = G->code_offset; pc < G->code_offset + G->code_len; pc++) {
       DECODE(c->code, pc);
+      if (op == ORC_OP_PMDS) {
+        uint64_t in[12];
+        for (int i = 0; i < 12; i++) in[i] = regs[ia + i];
+        for (int r = 0; r < 12; r++) {
+          uint64_t v = gl_add(c->imm[ib + r], gl_mul(in[r], PMDS_DIAG[r]));
+          for (int i = 0; i < 12; i++) v = gl_add(v, gl_mul(in[(i + r) % 12], PMDS_CIRC[i]));
+          regs[dst + r] = v;
+        }
+        continue;
+      }
       uint64_t a = operand_b(c, ka, ia, regs, wires, consts, pis);
       if (op == ORC_OP_EMIT || op == ORC_OP_EMITBOOL) {
         if (op == ORC_OP_EMITBOOL) a = gl_sub(gl_mul(a, a), a);
-        for (uint32_t k = 0; k < CH; k++) acc[k] = gl_add(gl_mul(acc[k], alphas[k]), a);
-        if (raw && (int)g == raw_gate) raw[G->num_constraints - 1 - emitted] = a;
+        for (uint32_t k = 0; k < CH; k++) {
+          if (fwd) { acc[k] = gl_add(acc[k], gl_mul(apow[k], a)); apow[k] = gl_mul(apow[k], alphas[k]); }
+          else acc[k] = gl_add(gl_mul(acc[k], alphas[k]), a);
+        }
+        if (raw && (int)g == raw_gate) raw[fwd ? emitted : G->num_constraints - 1 - emitted] = a;
         emitted++;
         continue;
       }
+      if (op == ORC_OP_SBOX) { regs[dst] = sbox7_b(a); continue; }
       uint64_t b = operand_b(c, kb, ib, regs, wires, consts, pis);
       switch (op) {
         case ORC_OP_ADD: regs[dst] = gl_add(a, b); break;
@@ -275,6 +301,7 @@ static inline gl2_t operand_e(const orc_circuit *c, uint32_t k, uint32_t i, cons
     default: return gl2_from_base(pis[i]);
   }
 }
+static inline gl2_t sbox7_e(gl2_t x) { gl2_t x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2), x3 = gl2_mul(x2, x); return gl2_mul(x3, x4); }
 static void eval_gates_ext(const orc_circuit *c, const gl2_t *wires, const gl2_t *consts, const uint64_t *pis,
                            const uint64_t *alphas, gl2_t *out) {
   uint32_t CH = c->p.num_challenges;
@@ -282,16 +309,32 @@ static void eval_gates_ext(const orc_circuit *c, const gl2_t *wires, const gl2_t
   gl2_t regs[ORC_MAX_REGS];
   for (uint32_t g = 0; g < c->num_gates; g++) {
     const orc_gate *G = &c->gates[g];
+    const int fwd = (G->flags & ORC_GATE_EMIT_FORWARD) != 0;
     gl2_t acc[4];
+    uint64_t apow[4] = {1, 1, 1, 1};
     for (int k = 0; k < 4; k++) acc[k] = gl2_from_base(0);
     for (uint32_t pc = G->code_offset; pc < G->code_offset + G->code_len; pc++) {
       DECODE(c->code, pc);
+      if (op == ORC_OP_PMDS) {
+        gl2_t in[12];
+        for (int i = 0; i < 12; i++) in[i] = regs[ia + i];
+        for (int r = 0; r < 12; r++) {
+          gl2_t v = gl2_add(gl2_from_base(c->imm[ib + r]), gl2_scale(in[r], PMDS_DIAG[r]));
+          for (int i = 0; i < 12; i++) v = gl2_add(v, gl2_scale(in[(i + r) % 12], PMDS_CIRC[i]));
+          regs[dst + r] = v;
+        }
+        continue;
+      }
       gl2_t a = operand_e(c, ka, ia, regs, wires, consts, pis);
       if (op == ORC_OP_EMIT || op == ORC_OP_EMITBOOL) {
         if (op == ORC_OP_EMITBOOL) a = gl2_sub(gl2_mul(a, a), a);
-        for (uint32_t k = 0; k < CH; k++) acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
+        for (uint32_t k = 0; k < CH; k++) {
+          if (fwd) { acc[k] = gl2_add(acc[k], gl2_scale(a, apow[k])); apow[k] = gl_mul(apow[k], alphas[k]); }
+          else acc[k] = gl2_add(gl2_scale(acc[k], alphas[k]), a);
+        }
         continue;
       }
+      if (op == ORC_OP_SBOX) { regs[dst] = sbox7_e(a); continue; }
       gl2_t b = operand_e(c, kb, ib, regs, wires, consts, pis);
       switch (op) {
         case ORC_OP_ADD: regs[dst] = gl2_add(a, b); break;
@@ -315,6 +358,8 @@ size_t orc_check_witness(const orc_circuit *c, const uint64_t *wires, const uint
   uint32_t W = c->p.num_wires, NC = c->p.num_constants;
   uint64_t *pis = (uint64_t *)xmalloc((c->npi + 1) * 8);
   for (uint32_t i = 0; i < c->npi; i++) pis[i] = gl_canon(pis_in[i]);
+  uint64_t pi_hash[4];
+  orc_hash_no_pad(pis, c->npi, pi_hash);
   uint64_t *w = (uint64_t *)xmalloc(W * 8), *k = (uint64_t *)xmalloc(NC * 8), *raw = (uint64_t *)xmalloc((c->max_gate_constraints + 1) * 8);
   uint64_t alphas[4] = {1, 1, 1, 1}, out[4];
   for (size_t r = 0; r < n; r++) {
@@ -323,7 +368,7 @@ size_t orc_check_witness(const orc_circuit *c, const uint64_t *wires, const uint
     for (uint32_t g = 0; g < c->num_gates; g++) {
       const orc_gate *G = &c->gates[g];
       if (k[G->selector_index] != G->selector_value) continue;
-      eval_gates_base(c, w, k, pis, alphas, out, (int)g, raw);
+      eval_gates_base(c, w, k, pi_hash, alphas, out, (int)g, raw);
       for (uint32_t i = 0; i < G->num_constraints; i++)
         if (raw[i]) { if (!bad && first_bad) { first_bad[0] = r; first_bad[1] = i; } bad++; }
     }
@@ -513,7 +558,7 @@ int orc_prove(const orc_circuit *cc, const uint64_t *wires_in, const uint64_t *p
   ch_observe_n(&ch, zb->tree->cap, L.capw);
   for (size_t k = 0; k < CH; k++) alphas[k] = ch_get(&ch);
 
-  uint64_t *qchunks = quotient_chunks(c, wb, zb, pis, betas, gammas, alphas);
+  uint64_t *qchunks = quotient_chunks(c, wb, zb, pi_hash, betas, gammas, alphas);
   orc_batch *qb = batch_from_coeffs_owned(qchunks, CH * Q, p->degree_bits, p->rate_bits, p->cap_height);
   memcpy(proof + L.quot_cap, qb->tree->cap, L.capw * 8);
   ch_observe_n(&ch, qb->tree->cap, L.capw);
@@ -755,7 +800,7 @@ int orc_verify(const orc_circuit *c, const uint64_t *proof, const uint64_t *pis_
       }
     }
     gl2_t gates[4];
-    eval_gates_ext(c, ow, oc, pis, alphas, gates);
+    eval_gates_ext(c, ow, oc, pi_hash, alphas, gates);
     for (size_t k = 0; k < CH; k++) {
       gl2_t acc = gates[k];
       for (size_t t = nt; t-- > 0;) acc = gl2_add(gl2_scale(acc, alphas[k]), terms[t]);

@@ -23,14 +23,19 @@ typedef struct {
   uint32_t group_start, group_end; /* selector values [start, end) share the column */
   uint32_t code_offset, code_len;  /* in instructions (2 words each) */
   uint32_t num_constraints;
+  uint32_t flags;           /* ORC_GATE_EMIT_FORWARD: the program emits its constraints from the first to the last */
 } orc_gate;
+#define ORC_GATE_EMIT_FORWARD 1u
 
 /* gate program instruction: word0 = op | dst << 8 | kind_a << 16 | kind_b << 20 ; word1 = idx_a | idx_b << 16 */
 enum { ORC_OP_ADD = 0, ORC_OP_SUB = 1, ORC_OP_MUL = 2, ORC_OP_EMIT = 3,
        ORC_OP_XOR = 4,      /* dst = a + b - 2ab */
        ORC_OP_DBLADD = 5,   /* dst = 2a + b */
        ORC_OP_EMITBOOL = 6, /* emits a*a - a */
-       ORC_OP_MULADD = 7 }; /* dst = dst + a*b */
+       ORC_OP_MULADD = 7,   /* dst = dst + a*b */
+       ORC_OP_SBOX = 8,     /* dst = a^7 (Poseidon S-box) */
+       ORC_OP_PMDS = 9 };   /* regs[dst..dst+12) = MDS * regs[idx_a..idx_a+12) + imm[idx_b..idx_b+12)  (Poseidon MDS layer + next constants) */
+/* ORC_K_PI: element idx (< 4) of public_inputs_hash = hash_no_pad(public inputs), what plonky2's PublicInputGate compares with */
 enum { ORC_K_REG = 0, ORC_K_WIRE = 1, ORC_K_CONST = 2, ORC_K_IMM = 3, ORC_K_PI = 4 };
 #define ORC_MAX_REGS 64
 #define ORC_UNUSED_SELECTOR 0xFFFFFFFFull

@@ -107,7 +107,7 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     lcp2_circuit *vc = nullptr;
     if (lcp2_verifier_create(&cd, digest, cap.data(), &vc) != LCP2_OK) throw std::runtime_error("lcp2_verifier_create failed");
     int failed = 0;
-    int rc = lcp2_verify(vc, oproof.data(), pis.data(), &failed);
+    int rc = lcp2_verify(vc, oproof.data(), oproof.size(), pis.data(), pis.size(), &failed);
     lcp2_circuit_destroy(vc);
     if (rc != LCP2_OK) throw std::runtime_error("product verifier rejected the oracle proof, check " + std::to_string(failed));
     printf("proved (oracle) and verified, degree_bits %u\n", data.degree_bits());

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"liblcp2.so does not export {n}"
-    assert lib.lcp2_abi_version() == 1
+    assert lib.lcp2_abi_version() == 2
 
 
 def test_standard_params_match_standard_recursion_config():

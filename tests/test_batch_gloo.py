@@ -44,9 +44,9 @@ def _worker(rank, world, port, num_updates, out_dir):
     circ, wires, pis = m.circuit.synthetic_circuit(params, seed=11)
     oc = oracle_lib.OracleCircuit(L, circ)
 
-    def witness(u):  # update u: the same circuit, a different witness (unconstrained column tagged with u)
+    def witness(u):  # update u: the same circuit, a different witness (free cells of the padding row tagged with u)
         w = wires.copy()
-        w[134] = np.uint64(u + 1)
+        m.circuit.tag_witness(w, u + 1)
         return w
 
     witness.num_updates = num_updates

@@ -71,9 +71,8 @@ def test_workspace_reuse_and_device_resident_witness(gpu_ctx, oracle):
     data = m.CircuitData.build(gpu_ctx, circ)
     want = oc.prove(wires, pis)
     assert (data.prove(wires, pis) == want).all()
-    # second witness on the same circuit: perturb an unconstrained (unrouted, unused) wire column
-    w2 = wires.copy()
-    w2[130] = np.arange(w2.shape[1], dtype=np.uint64)
+    # second witness on the same circuit: the free cells of the NoopGate padding row
+    w2 = m.circuit.tag_witness(wires.copy(), 0xC0FFEE)
     assert oc.check_witness(w2, pis)[0] == 0
     want2 = oc.prove(w2, pis)
     assert (want2 != want).any()
@@ -86,20 +85,79 @@ def test_workspace_reuse_and_device_resident_witness(gpu_ctx, oracle):
     oc.close()
 
 
-def test_unsatisfied_witness_gives_rejected_proof(gpu_ctx, oracle):
+def test_unsatisfied_witness_is_an_error(gpu_ctx, oracle):
+    """prove() of an unsatisfiable witness is an Err in plonky2 (the reference's #[should_panic] tests): lcp2_prove returns
+    LCP2_E_UNSAT for a violated gate constraint (checked over the rows of H on the device) and for a broken copy constraint
+    (the permutation product does not return to 1); the same witness unbroken proves."""
     import eth_lc_plonky2_amd as m
     params = m.standard_params(7, 4)
     circ, wires, pis = m.circuit.synthetic_circuit(params, seed=8)
-    wires[7, 20] ^= np.uint64(1)
     data = m.CircuitData.build(gpu_ctx, circ)
-    proof = data.prove(wires, pis)
     oc = oracle_lib.OracleCircuit(oracle, circ)
-    assert (proof == oc.prove(wires, pis)).all()  # garbage in, identical garbage out
-    with pytest.raises(m.ProofRejected) as e:
-        data.verify(proof, pis)
-    assert e.value.check == 3
+    arith = int(np.nonzero(circ.constants_sigmas[0] == circ.gateset.index("ArithmeticGate"))[0][3])
+    bad = wires.copy()
+    bad[7, arith] ^= np.uint64(1)          # an ArithmeticGate output
+    assert oc.check_witness(bad, pis)[0] > 0
+    with pytest.raises(m.Lcp2Error) as e:
+        data.prove(bad, pis)
+    assert e.value.status == -5 and "gate constraint" in str(e.value) and ("row %d" % arith) in str(e.value)
+    # a copy constraint: the first arithmetic row's copy of public input 0 changed together with the product it feeds, so
+    # that every gate constraint still holds
+    first = int(np.nonzero(circ.constants_sigmas[0] == circ.gateset.index("ArithmeticGate"))[0][0])
+    bad = wires.copy()
+    bad[1, first] = np.uint64(12345)
+    c0, c1 = (int(circ.constants_sigmas[2 + k, first]) for k in (0, 1))
+    P = m.GOLDILOCKS_P
+    bad[3, first] = np.uint64((c0 * int(bad[0, first]) * 12345 + c1 * int(bad[2, first])) % P)
+    second = int(np.nonzero(circ.constants_sigmas[0] == circ.gateset.index("ArithmeticGate"))[0][1])
+    c0s, c1s = (int(circ.constants_sigmas[2 + k, second]) for k in (0, 1))
+    bad[0, second] = bad[3, first]
+    bad[3, second] = np.uint64((c0s * int(bad[0, second]) * int(bad[1, second]) + c1s * int(bad[2, second])) % P)
+    assert oc.check_witness(bad, pis)[0] == 0  # gate constraints hold
+    with pytest.raises(m.Lcp2Error) as e:
+        data.prove(bad, pis)
+    assert e.value.status == -5 and "copy constraint" in str(e.value)
+    got = data.prove(wires, pis)           # the handle is still usable
+    assert (got == oc.prove(wires, pis)).all()
     data.close()
     oc.close()
+
+
+def test_native_gate_claim_is_checked_at_build(gpu_ctx, oracle):
+    """LCP2_GATE_NATIVE_POSEIDON is a claim of the caller: build() runs the gate's program and the native evaluator on random
+    points and refuses a program that is not plonky2's PoseidonGate (here: one round constant off, one wire index off); with
+    the flag cleared the same description is interpreted, and both forms give the oracle's proof."""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(6, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=21)
+    gs = circ.gateset
+    pg = gs.gates[gs.index("PoseidonGate")]
+    assert pg.flags & m.circuit.GATE_NATIVE_POSEIDON
+    want = oracle_lib.OracleCircuit(oracle, circ).prove(wires, pis)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    assert (data.prove(wires, pis) == want).all()
+    data.close()
+    # the same gate interpreted instruction by instruction
+    pg.flags &= ~m.circuit.GATE_NATIVE_POSEIDON
+    data = m.CircuitData.build(gpu_ctx, circ)
+    assert (data.prove(wires, pis) == want).all()
+    data.close()
+    pg.flags |= m.circuit.GATE_NATIVE_POSEIDON
+    # a program that is not PoseidonGate must not get the native path
+    k = int(np.nonzero(gs.imm == np.uint64(m.poseidon_py.round_constants()[200]))[0][0])
+    gs.imm[k] ^= np.uint64(1)
+    with pytest.raises(m.Lcp2Error) as e:
+        m.CircuitData.build(gpu_ctx, circ)
+    assert e.value.status == -1 and "NATIVE" in str(e.value)
+    gs.imm[k] ^= np.uint64(1)
+    code = gs.code
+    pc = pg.code_offset + pg.code_len - 2   # the last SUB: state[11] - wire_output(11)
+    assert code[2 * pc] & 0xF == m.circuit.OP_SUB
+    code[2 * pc + 1] ^= np.uint32(1 << 16)  # compare with a neighbouring wire instead
+    with pytest.raises(m.Lcp2Error):
+        m.CircuitData.build(gpu_ctx, circ)
+    code[2 * pc + 1] ^= np.uint32(1 << 16)
+    m.CircuitData.build(gpu_ctx, circ).close()
 
 
 @pytest.mark.parametrize("round_", range(8))
@@ -238,7 +296,7 @@ def test_staged_seams_compose_to_prove(gpu_ctx, oracle):
     proof[capw:2 * capw] = data.perm_zs(betas, gammas).ravel()
     t.observe(proof[capw:2 * capw])
     alphas = t.get(2)
-    proof[2 * capw:3 * capw] = data.quotient(alphas, pis).ravel()
+    proof[2 * capw:3 * capw] = data.quotient(alphas, pi_hash).ravel()
     t.observe(proof[2 * capw:3 * capw])
     zeta = t.get(2)
     assert list(zeta) == list(ch["zeta"])

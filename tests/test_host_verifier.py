@@ -71,7 +71,7 @@ def test_verifier_create_validates_gate_programs(oracle):
     first = next(g for g in circ.gateset.gates if g.code_len).code_offset
     saved = (int(code[2 * first]), int(code[2 * first + 1]))
     try:
-        for w0, w1 in [((saved[0] & ~0xF) | 9, saved[1]),                    # unknown opcode
+        for w0, w1 in [((saved[0] & ~0xF) | 15, saved[1]),                   # unknown opcode
                        ((saved[0] & ~0xFF00) | (200 << 8), saved[1]),         # destination register out of range
                        ((saved[0] & ~0xF0000) | (1 << 16), 0xFFFF)]:          # wire operand out of range
             code[2 * first], code[2 * first + 1] = w0, w1
@@ -81,4 +81,107 @@ def test_verifier_create_validates_gate_programs(oracle):
     finally:
         code[2 * first], code[2 * first + 1] = saved
     m.CircuitData.verifier_only(circ, digest, cap).close()
+    oc.close()
+
+
+def _variant(m, base_bits, **kw):
+    p = m.standard_params(base_bits, 4)
+    for k, v in kw.items():
+        if k == "fri_arity_bits":
+            p.num_fri_layers = len(v)
+            for i in range(8):
+                p.fri_arity_bits[i] = v[i] if i < len(v) else 0
+        else:
+            setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("kw", [
+    dict(fri_arity_bits=[6]),            # arity 64: the verifier's interpolation arrays hold 32 points
+    dict(cap_height=9),                  # above the LDE tree of a 2^5-row circuit: sibling counts would underflow
+    dict(quotient_degree_factor=0),
+    dict(proof_of_work_bits=0),          # a shift by 64
+    dict(degree_bits=40),
+    dict(num_query_rounds=65),
+    dict(num_challenges=3),
+    dict(num_routed_wires=200),
+])
+def test_verifier_create_checks_the_parameters(oracle, kw):
+    """lcp2_verifier_create runs the same shape checks as lcp2_circuit_create: the verifier indexes fixed-size arrays with
+    them and trusts nothing else about an untrusted description."""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(5, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    digest, cap = oc.digest()
+    oc.close()
+    good = circ.params
+    try:
+        circ.params = _variant(m, 5, **kw)
+        with pytest.raises(m.Lcp2Error) as e:
+            m.CircuitData.verifier_only(circ, digest, cap)
+        assert e.value.status in (-1, -6)
+    finally:
+        circ.params = good
+
+
+def test_verify_refuses_a_proof_of_the_wrong_length(oracle):
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(5, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=4)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    proof = oc.prove(wires, pis)
+    vd = m.CircuitData.verifier_only(circ, *oc.digest())
+    vd.verify(proof, pis)
+    for bad in (proof[:-1], proof[:100], np.concatenate([proof, proof[:1]])):
+        with pytest.raises(m.Lcp2Error) as e:
+            vd.verify(bad, pis)
+        assert e.value.status == -1 and not isinstance(e.value, m.ProofRejected)
+    with pytest.raises(m.Lcp2Error) as e:
+        vd.verify(proof, pis[:-1])
+    assert e.value.status == -1
+    oc.close()
+    vd.close()
+
+
+def test_challenger_rejects_a_full_input_buffer():
+    """a Challenger never holds 8 buffered inputs (it duplexes at the eighth): a state that claims so is corrupt"""
+    import ctypes
+    import eth_lc_plonky2_amd as m
+    ch = m.binding.Challenger()
+    ch.observe([1, 2, 3])
+    ch.state.input_len = 8
+    with pytest.raises(m.Lcp2Error):
+        ch.observe([4])
+    with pytest.raises(m.Lcp2Error):
+        ch.get(1)
+    ch.state.input_len = 3
+    ch.observe([4])
+    assert ch.get(1).size == 1
+
+
+def test_plonky2_gate_programs_hold_on_their_witness_rows(oracle):
+    """The programs of plonky2's gates (circuit.py) vanish on rows filled by the matching generators: a PoseidonGate row
+    from poseidon_py.gate_row (swap 0 and 1), a BaseSumGate row of bits, ConstantGate / ArithmeticGate / PublicInputGate rows."""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import poseidon_py as pos
+    params = m.standard_params(6, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=9, npi=11)  # 11 inputs: two sponge blocks
+    gs = circ.gateset
+    assert gs.names == ["NoopGate", "ConstantGate", "PublicInputGate", "BaseSumGate", "ArithmeticGate", "PoseidonGate"]
+    assert [g.num_constraints for g in gs.gates] == [0, 2, 4, 64, 20, 123] and gs.num_selectors == 2
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    assert oc.check_witness(wires, pis)[0] == 0
+    # the in-circuit hash is the transcript's hash
+    want = np.zeros(4, dtype=np.uint64)
+    oracle.orc_hash_no_pad(oracle_lib.vp(np.ascontiguousarray(pis)), len(pis), oracle_lib.vp(want))
+    assert list(wires[:4, 0]) == list(want) == pos.hash_no_pad(pis)
+    # a swapped PoseidonGate row satisfies the gate too: put one on a Poseidon row's place
+    prow = int(np.nonzero(circ.constants_sigmas[1] == gs.index("PoseidonGate"))[0][0])
+    w2 = wires.copy()
+    w2[:135, prow] = np.array(pos.gate_row(list(range(1, 13)), 1), dtype=np.uint64)
+    bad, first = oc.check_witness(w2, pis)
+    assert bad == 0  # check_witness looks at gate constraints only (copy constraints are the permutation argument's job)
+    w2[pos.W_DELTA, prow] ^= np.uint64(1)
+    assert oc.check_witness(w2, pis)[0] > 0
     oc.close()
