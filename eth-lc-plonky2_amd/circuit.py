@@ -27,7 +27,8 @@ K_REG, K_WIRE, K_CONST, K_IMM, K_PI = 0, 1, 2, 3, 4
 UNUSED_SELECTOR = 0xFFFFFFFF
 MAX_REGS = 64
 GATE_EMIT_FORWARD = 1
-GATE_NATIVE_POSEIDON = 0x100  # the claim "this program is plonky2's PoseidonGate": checked by lcp2_circuit_create against its native evaluator
+# "this program is plonky2's X gate": claims that lcp2_circuit_create checks against its native evaluators (include/lcp2.h)
+GATE_NATIVE_POSEIDON, GATE_NATIVE_ARITHMETIC, GATE_NATIVE_BASE_SUM2 = 0x100, 0x200, 0x300
 
 
 class Gate(ctypes.Structure):
@@ -175,6 +176,7 @@ ARITH_OPS = 20
 def gate_arithmetic(asm):
     """ArithmeticGate { num_ops: 20 } (gates/arithmetic_base.rs): output - (c0 * multiplicand_0 * multiplicand_1 + c1 * addend)
     over wires 4i .. 4i+3 = multiplicand_0, multiplicand_1, addend, output."""
+    asm.flags |= GATE_NATIVE_ARITHMETIC
     for k in reversed(range(ARITH_OPS)):
         xy = asm.mul(W(4 * k), W(4 * k + 1))
         t = asm.mul(xy, C(0))
@@ -192,6 +194,7 @@ def gate_base_sum(num_limbs=BASE_SUM_LIMBS):
     """BaseSumGate<2> { num_limbs } (gates/base_sum.rs): wire 0 = sum, wires 1 .. num_limbs = little-endian bits.
     constraints: [reduce_with_powers(limbs, 2) - sum] ++ [limb * (limb - 1) for every limb]"""
     def build(asm):
+        asm.flags |= GATE_NATIVE_BASE_SUM2
         for i in reversed(range(num_limbs)):
             asm.emit_bool(W(1 + i))
         acc = asm.dbladd(W(num_limbs), W(num_limbs - 1))

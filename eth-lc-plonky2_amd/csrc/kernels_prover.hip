@@ -301,11 +301,16 @@ __device__ u64 q_sbox(u64 x);
 struct QEmit {
   u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
   u32 CH, emitted;
-  __device__ __forceinline__ void operator()(u64 x) {
+  __device__ __forceinline__ void operator()(u64 x) {  // forward gates: Horner with 1 / alpha (step = 0 encodes alpha = 0)
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
       if (c < CH) acc[c] = step[c] == 0 ? (emitted ? acc[c] : x) : gl_add(gl_mul(acc[c], step[c]), x);
     emitted++;
+  }
+  __device__ __forceinline__ void horner(u64 x) {      // constraints listed last to first: Horner with alpha
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < CH) acc[c] = gl_add(gl_mul(acc[c], step[c]), x);
   }
 };
 __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {
@@ -358,9 +363,9 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
 #pragma unroll
       for (u32 j = 0; j < QUOTIENT_STAGE; j++) pw[j] = W[(u64)(65 + min(r + j, (u32)POS_PARTIAL - 1)) * st];
 #pragma unroll
-      for (u32 j = 0; j < QUOTIENT_STAGE; j++) lds[(a.num_regs + j) * T + tid] = pw[j];
+      for (u32 j = 0; j < QUOTIENT_STAGE; j++) lds[j * T + tid] = pw[j];  // slots [0, QUOTIENT_STAGE): this kernel has no interpreter registers
     }
-    const u64 w = lds[(a.num_regs + (r % QUOTIENT_STAGE)) * T + tid];
+    const u64 w = lds[(r % QUOTIENT_STAGE) * T + tid];
     emit(gl_sub(gl_canon(((u64)hi[0] << 32) | lo[0]), w));
     lo[0] = (u32)w; hi[0] = (u32)(w >> 32);
     pos_sbox_h(lo[0], hi[0], k);
@@ -387,90 +392,173 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
 }
 #endif
 
-// res[c] <- sum_g filter_g(point) * sum_i alpha_c^i constraint_{g,i}(point) for the point whose operands sit at index i
-__device__ __forceinline__ void q_eval_gates(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, u64 res[QUOTIENT_MAX_CH]) {
+// ---- native ArithmeticGate { num_ops } (gates/arithmetic_base.rs): output - (c0 * m0 * m1 + c1 * addend) per operation, wires
+// 4k .. 4k+3.  Constraints are folded last to first (plain Horner with alpha), four operations = 16 wire loads per batch.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void q_arithmetic_native(const QuotientArgs &a, u64 i, u32 num_ops, QEmit &emit) {
+  const u64 *W = a.wires + i;
+  const u64 st = a.stride;
+  const u64 c0 = a.consts[(u64)a.num_selectors * st + i], c1 = a.consts[(u64)(a.num_selectors + 1) * st + i];
+  for (int top = (int)num_ops; top > 0; top -= 4) {  // operations [top - 4, top), clamped at 0
+    const int first = top >= 4 ? top - 4 : 0;
+    u64 w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = W[(u64)min(4 * first + j, 4 * (int)num_ops - 1) * st];  // a short last batch re-reads its last wire
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      if (first + k < top) {
+        const u64 comp = gl_add(gl_mul(gl_mul(w[4 * k], w[4 * k + 1]), c0), gl_mul(w[4 * k + 2], c1));
+        emit(gl_sub(w[4 * k + 3], comp));
+      }
+    }
+  }
+}
+// ---- native BaseSumGate<2> { num_limbs } (gates/base_sum.rs): constraints [sum_i 2^i limb_i - wire_0, limb_i^2 - limb_i ...],
+// folded last to first: the limb constraints from the top limb down (the recomposition is the same walk), then the sum.
+__device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i, u32 num_limbs, QEmit &emit) {
+  const u64 *W = a.wires + i;
+  const u64 st = a.stride;
+  u64 sum = 0;
+  for (int top = (int)num_limbs; top > 0; top -= 16) {  // limbs [top - 16, top) = wires [top - 15, top]
+    u64 w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int l = top - 1 - j; w[j] = W[(u64)(1 + (l > 0 ? l : 0)) * st]; }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (top - 1 - j >= 0) {
+        emit(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        sum = gl_add(gl_add(sum, sum), w[j]);
+      }
+    }
+  }
+  emit(gl_sub(sum, W[0]));
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+}  // namespace lcp2
+#include "generated_gates.hpp"
+namespace lcp2 {
+static_assert(Q_GENERATED_COUNT == QUOTIENT_GENERATED_GATES, "prover_kernels.hpp and generated_gates.hpp disagree");
+#endif
+
+// val[c] <- filter_g(point) * sum_i alpha_c^i constraint_{g,i}(point) for gate g at the point whose operands sit at index i.
+// NATIVE = 0 interprets the gate's program, LCP2_GATE_NATIVE_* runs the native evaluator of that plonky2 gate.
+template <u32 NATIVE>
+__device__ __forceinline__ void q_gate_value(const QuotientArgs &a, u32 g, const GateDev &G, u64 i, u64 *lds, u32 T, u32 tid, u64 val[QUOTIENT_MAX_CH]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const u32 CH = a.num_challenges;
+  const bool fwd = (G.flags & LCP2_GATE_EMIT_FORWARD) != 0;
+  // Horner step with alpha (constraints listed last to first) or with 1 / alpha (first to last; rescaled below).
+  // alpha = 0 in a forward gate (step = 0): the sum is the first constraint alone.
+  QEmit emit;
+  emit.CH = CH; emit.emitted = 0;
 #pragma unroll
-  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) res[c] = 0;
-  for (u32 g = 0; g < a.num_gates; g++) {
-    GateDev G;  // field by field: an address-space-qualified struct has no implicit copy
-    {
-      const_as<u32> gw = konst((const u32 *)a.gates) + (size_t)g * (sizeof(GateDev) / 4);
-      G.selector_index = gw[0]; G.selector_value = gw[1]; G.group_start = gw[2]; G.group_end = gw[3];
-      G.code_offset = gw[4]; G.code_len = gw[5]; G.num_constraints = gw[6]; G.flags = gw[7];
-    }
-    const bool fwd = (G.flags & LCP2_GATE_EMIT_FORWARD) != 0;
-    // Horner step with alpha (constraints listed last to first) or with 1 / alpha (first to last; rescaled below).
-    // alpha = 0 in a forward gate (step = 0): the sum is the first constraint alone.
-    QEmit emit;
-    emit.CH = CH; emit.emitted = 0;
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { emit.acc[c] = 0; emit.step[c] = c < CH ? (fwd ? konst(a.alpha_inv)[c] : konst(a.alphas)[c]) : 0; }
-    if (a.use_native && (G.flags & LCP2_GATE_NATIVE_MASK) == LCP2_GATE_NATIVE_POSEIDON) {
-      q_poseidon_native(a, i, lds, T, tid, emit);
-    } else {
-      // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
-      // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
-      const_as<u64> code2 = konst((const u64 *)a.code);  // one instruction = two 32-bit words
-      u64 nxt = code2[G.code_offset];
-      for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
-        const u32 w0 = (u32)nxt, w1 = (u32)(nxt >> 32);
-        nxt = code2[pc + 1];
-        const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
-        if (op == QOP_LDG) { q_stage(a, dst, konst(a.stage_list) + w1, lds, T, tid, i); continue; }
-        if (op == LCP2_OP_PMDS) { q_pmds(lds, T, tid, dst, ia, konst(a.imm) + ib); continue; }
-        u64 x = q_operand(a, ka, ia, lds, T, tid, i);
-        if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
-          if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
-          if (fwd) emit(x);
-          else {  // step != 0 is not required here: plain Horner with alpha
-#pragma unroll
-            for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-              if (c < CH) emit.acc[c] = gl_add(gl_mul(emit.acc[c], emit.step[c]), x);
-          }
-          continue;
-        }
-        if (op == LCP2_OP_SBOX) { lds[dst * T + tid] = q_sbox(x); continue; }
-        u64 y = q_operand(a, kb, ib, lds, T, tid, i);
-        u64 r;
-        switch (op) {  // uniform across the wave: the code stream is the same for every point
-          case LCP2_OP_ADD: r = gl_add(x, y); break;
-          case LCP2_OP_SUB: r = gl_sub(x, y); break;
-          case LCP2_OP_MUL: r = gl_mul(x, y); break;
-          case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
-          case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
-          default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
-        }
-        lds[dst * T + tid] = r;
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { emit.acc[c] = 0; emit.step[c] = c < CH ? (fwd ? konst(a.alpha_inv)[c] : konst(a.alphas)[c]) : 0; }
+  if (NATIVE == LCP2_GATE_NATIVE_POSEIDON) {
+    q_poseidon_native(a, i, lds, T, tid, emit);
+  } else if (NATIVE == LCP2_GATE_NATIVE_ARITHMETIC) {
+    q_arithmetic_native(a, i, G.num_constraints, emit);
+  } else if (NATIVE == LCP2_GATE_NATIVE_BASE_SUM2) {
+    q_base_sum2_native(a, i, G.num_constraints - 1, emit);
+  } else if (NATIVE & 0x8000u) {
+    q_generated<(NATIVE >> 8) & 0x7Fu>(a, i, emit);
+  } else {
+    // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
+    // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
+    const_as<u64> code2 = konst((const u64 *)a.code);  // one instruction = two 32-bit words
+    u64 nxt = code2[G.code_offset];
+    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
+      const u32 w0 = (u32)nxt, w1 = (u32)(nxt >> 32);
+      nxt = code2[pc + 1];
+      const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
+      if (op == QOP_LDG) { q_stage(a, dst, konst(a.stage_list) + w1, lds, T, tid, i); continue; }
+      if (op == LCP2_OP_PMDS) { q_pmds(lds, T, tid, dst, ia, konst(a.imm) + ib); continue; }
+      u64 x = q_operand(a, ka, ia, lds, T, tid, i);
+      if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
+        if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
+        if (fwd) emit(x); else emit.horner(x);
+        continue;
       }
-    }
-    u64 s = a.consts[(u64)G.selector_index * a.stride + i];
-    u64 f = 1;
-    for (u32 j = G.group_start; j < G.group_end; j++)
-      if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
-    if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) {
-        const u64 sum = (fwd && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
-        res[c] = gl_add(res[c], gl_mul(f, sum));
+      if (op == LCP2_OP_SBOX) { lds[dst * T + tid] = q_sbox(x); continue; }
+      u64 y = q_operand(a, kb, ib, lds, T, tid, i);
+      u64 r;
+      switch (op) {  // uniform across the wave: the code stream is the same for every point
+        case LCP2_OP_ADD: r = gl_add(x, y); break;
+        case LCP2_OP_SUB: r = gl_sub(x, y); break;
+        case LCP2_OP_MUL: r = gl_mul(x, y); break;
+        case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
+        case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
+        default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
       }
+      lds[dst * T + tid] = r;
+    }
   }
+  const u64 s = a.consts[(u64)G.selector_index * a.stride + i];
+  u64 f = 1;
+  for (u32 j = G.group_start; j < G.group_end; j++)
+    if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
+  if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+    if (c < CH) {
+      const u64 sum = (fwd && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
+      val[c] = gl_mul(f, sum);
+    }
 #endif
 }
+__device__ __forceinline__ GateDev q_load_gate(const QuotientArgs &a, u32 g) {
+  GateDev G;  // field by field: an address-space-qualified struct has no implicit copy
+  const_as<u32> gw = konst((const u32 *)a.gates) + (size_t)g * (sizeof(GateDev) / 4);
+  G.selector_index = gw[0]; G.selector_value = gw[1]; G.group_start = gw[2]; G.group_end = gw[3];
+  G.code_offset = gw[4]; G.code_len = gw[5]; G.num_constraints = gw[6]; G.flags = gw[7];
+  return G;
+}
 
-__global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
+// K6 is one launch per gate type plus the permutation pass: every kernel carries only the registers its gate needs (the native
+// PoseidonGate wants ~120 VGPRs, the permutation pass ~90, an interpreted gate ~80), so none drags the others' occupancy down,
+// and an interpreted gate's LDS registers are not allocated beside a native one.  A gate kernel adds filter * constraints into
+// out[c][point] (the first one of a proof stores); the extra traffic is 32 bytes per point and launch, ~1.5 % of what K6 reads.
+// CHECK = true is the same evaluation over the rows of H (lcp2_prove's LCP2_E_UNSAT): on a row only its own gate has a
+// non-zero filter, so a wave skips a gate that none of its rows holds, and a non-zero value is a violated constraint.
+template <u32 NATIVE, bool CHECK>
+__global__ __launch_bounds__(QUOTIENT_THREADS, NATIVE == LCP2_GATE_NATIVE_POSEIDON ? 2 : 2) void k_q_gate(QuotientArgs a, u32 g, u32 accumulate, unsigned long long *flag) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
+  const u64 i0 = (u64)blockIdx.x * T + tid;
+  if (!CHECK && i0 >= a.count) return;            // no barrier is used below
+  const u64 i = i0 < a.count ? i0 : a.count - 1;  // CHECK: the tail re-checks the last row so that every lane votes
+  const GateDev G = q_load_gate(a, g);
+  if (CHECK) {
+    const u64 sel = a.consts[(u64)G.selector_index * a.stride + i];
+    if (!__any(sel == G.selector_value)) return;
+  }
+  u64 val[QUOTIENT_MAX_CH];
+  q_gate_value<NATIVE>(a, g, G, i, lds, T, tid, val);
+  if (CHECK) {
+    bool bad = false;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < a.num_challenges && val[c] != 0) bad = true;
+    if (bad) atomicMin(flag, (unsigned long long)i + 1);
+  } else {
+    const u64 ig = a.leaf0 + i;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < a.num_challenges) a.out[(u64)c * a.N + ig] = accumulate ? gl_add(a.out[(u64)c * a.N + ig], val[c]) : val[c];
+  }
+}
+
+// permutation argument + division by Z_H: out[c][point] holds the sum of the gate terms on entry, the quotient value on exit
+__global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_perm(QuotientArgs a, u32 have_gates) {
+  const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i = (u64)blockIdx.x * T + tid;  // local storage (leaf) index; global index = a.leaf0 + i
-  if (i >= a.count) return;                  // no barrier is used below
+  if (i >= a.count) return;
   const u64 ig = a.leaf0 + i;
   const u32 CH = a.num_challenges;
   u64 res[QUOTIENT_MAX_CH];
-
-  // ---- gate constraints: sum_g filter_g * sum_i alpha^i c_{g,i}
-  q_eval_gates(a, i, lds, T, tid, res);
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) res[c] = (c < CH && have_gates) ? a.out[(u64)c * a.N + ig] : 0;
 
   // ---- permutation argument terms, folded in front of the gate constraints:
   //   terms = [ L0 (Z_c - 1) ]_c ++ [ prev * prod num - next * prod den ]_{c,k} ;  out = sum_t alpha^t terms_t + alpha^nt * gates
@@ -559,51 +647,71 @@ __global__ __launch_bounds__(QUOTIENT_THREADS) void k_quotient(QuotientArgs a) {
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
     if (c < CH) a.out[(u64)c * a.N + ig] = gl_mul(res[c], zhi);
 }
-void launch_quotient(hipStream_t s, const QuotientArgs &a) {
-  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);  // the programs' registers + the operand staging slots
-  hipLaunchKernelGGL(k_quotient, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a);
-}
 
-// The gate programs over the rows of H: on a row only its own gate has a non-zero filter, so the filtered combination is
-// zero for every alpha exactly when that gate's constraints hold there (up to the 2^-64 chance of a bad alpha).
-__global__ __launch_bounds__(QUOTIENT_THREADS) void k_gate_check(QuotientArgs a, unsigned long long *flag) {
+// build()-time check of a native evaluator against the program it claims to be (random points in a.wires / a.consts)
+template <u32 NATIVE>
+__global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_native_check(QuotientArgs a, u32 g, unsigned long long *flag) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i = (u64)blockIdx.x * T + tid;
   if (i >= a.count) return;
-  u64 res[QUOTIENT_MAX_CH];
-  q_eval_gates(a, i, lds, T, tid, res);
-  bool bad = false;
-#pragma unroll
-  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-    if (c < a.num_challenges && res[c] != 0) bad = true;
-  if (bad) atomicMin(flag, (unsigned long long)i + 1);
-}
-// build()-time check of the native evaluators against the programs they claim to be (random points in a.wires / a.consts)
-__global__ __launch_bounds__(QUOTIENT_THREADS) void k_native_check(QuotientArgs a, unsigned long long *flag) {
-  extern __shared__ __attribute__((aligned(16))) u64 lds[];
-  const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
-  const u64 i = (u64)blockIdx.x * T + tid;
-  if (i >= a.count) return;
+  const GateDev G = q_load_gate(a, g);
   u64 r0[QUOTIENT_MAX_CH], r1[QUOTIENT_MAX_CH];
-  QuotientArgs b = a;
-  b.use_native = 0;
-  q_eval_gates(b, i, lds, T, tid, r0);
-  b.use_native = 1;
-  q_eval_gates(b, i, lds, T, tid, r1);
+  q_gate_value<0>(a, g, G, i, lds, T, tid, r0);
+  q_gate_value<NATIVE>(a, g, G, i, lds, T, tid, r1);
   bool bad = false;
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
     if (c < a.num_challenges && r0[c] != r1[c]) bad = true;
   if (bad) atomicMin(flag, (unsigned long long)i + 1);
 }
-void launch_native_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag) {
-  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
-  hipLaunchKernelGGL(k_native_check, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a, flag);
+
+namespace {
+template <bool CHECK>
+void launch_gate(hipStream_t s, const QuotientArgs &a, const GateDev &G, u32 g, u32 accumulate, unsigned long long *flag) {
+  const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
+  const size_t stage = (size_t)QUOTIENT_STAGE * QUOTIENT_THREADS * sizeof(u64), interp = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  switch (a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0) {
+    case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_POSEIDON, CHECK>), grid, block, stage, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_ARITHMETIC: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_ARITHMETIC, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_BASE_SUM2: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_BASE_SUM2, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(0), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(1), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(2), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(3), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    default: hipLaunchKernelGGL((k_q_gate<0, CHECK>), grid, block, interp, s, a, g, accumulate, flag); break;
+  }
 }
-void launch_gate_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag) {
-  size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
-  hipLaunchKernelGGL(k_gate_check, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), lds, s, a, flag);
+}  // namespace
+
+// host_gates: the gate table as uploaded (staged code offsets); gates without constraints are skipped
+void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates) {
+  u32 launched = 0;
+  for (u32 g = 0; g < host_gates.size(); g++) {
+    if (host_gates[g].num_constraints == 0) continue;
+    launch_gate<false>(s, a, host_gates[g], g, launched ? 1u : 0u, nullptr);
+    launched++;
+  }
+  hipLaunchKernelGGL(k_q_perm, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), 0, s, a, launched ? 1u : 0u);
+}
+void launch_gate_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
+  for (u32 g = 0; g < host_gates.size(); g++)
+    if (host_gates[g].num_constraints) launch_gate<true>(s, a, host_gates[g], g, 0, flag);
+}
+void launch_native_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
+  const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
+  const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  for (u32 g = 0; g < host_gates.size(); g++)
+    switch (host_gates[g].flags & LCP2_GATE_NATIVE_MASK) {
+      case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_POSEIDON>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_ARITHMETIC: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_ARITHMETIC>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_BASE_SUM2: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_BASE_SUM2>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(0)>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(1)>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(2)>), grid, block, lds, s, a, g, flag); break;
+      case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(3)>), grid, block, lds, s, a, g, flag); break;
+      default: break;
+    }
 }
 
 // ------------------------------------------------------------------ K7a: evaluate coefficient polynomials at an extension point

@@ -16,6 +16,7 @@ struct lcp2_circuit {
   lcp2_ctx *ctx = nullptr;
   lcp2_params p{};
   uint32_t npi = 0, num_selectors = 0, num_regs = 1, dev_regs = 1;
+  std::vector<GateDev> dev_gates;  // the gate table as uploaded: offsets into the staged code
   std::vector<lcp2_gate> gates;
   std::vector<uint32_t> code;
   std::vector<u64> imm, k_is;
@@ -117,9 +118,21 @@ static const char *validate_programs(const lcp2_circuit_desc *d) {
     if (G.selector_index >= d->num_selectors || ((size_t)G.code_offset + (size_t)G.code_len) * 2 > d->code_words || G.group_end < G.group_start ||
         (G.flags & ~(LCP2_GATE_EMIT_FORWARD | LCP2_GATE_NATIVE_MASK)))
       return "gate descriptor out of range";
-    if ((G.flags & LCP2_GATE_NATIVE_MASK) != 0) {
-      if ((G.flags & LCP2_GATE_NATIVE_MASK) != LCP2_GATE_NATIVE_POSEIDON) return "unknown native gate id";
-      if (!(G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints != 123 || p.num_wires < 135) return "LCP2_GATE_NATIVE_POSEIDON needs 135 wires, 123 forward-emitted constraints";
+    switch (G.flags & LCP2_GATE_NATIVE_MASK) {
+      case 0: break;
+      case LCP2_GATE_NATIVE_POSEIDON:
+        if (!(G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints != 123 || p.num_wires < 135) return "LCP2_GATE_NATIVE_POSEIDON needs 135 wires, 123 forward-emitted constraints";
+        break;
+      case LCP2_GATE_NATIVE_ARITHMETIC:
+        if ((G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints == 0 || 4 * (size_t)G.num_constraints > p.num_wires || p.num_constants - d->num_selectors < 2)
+          return "LCP2_GATE_NATIVE_ARITHMETIC needs 4 wires per operation and 2 gate constants";
+        break;
+      case LCP2_GATE_NATIVE_BASE_SUM2:
+        if ((G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints < 2 || G.num_constraints > p.num_wires) return "LCP2_GATE_NATIVE_BASE_SUM2 needs num_limbs + 1 wires";
+        break;
+      default:
+        if (!(G.flags & 0x8000u) || ((G.flags >> 8) & 0x7Fu) >= QUOTIENT_GENERATED_GATES || (G.flags & LCP2_GATE_EMIT_FORWARD)) return "unknown native gate id";
+        break;
     }
     size_t emits_seen = 0;
     for (size_t pc = G.code_offset; pc < (size_t)G.code_offset + G.code_len; pc++) {
@@ -201,7 +214,7 @@ static int check_native_gates(lcp2_circuit *c) {
   a.imm = c->d_imm.u(); a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.stage_list = (const u32 *)c->d_stage.p;
   a.num_wires = p.num_wires; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors; a.num_constants = p.num_constants;
   a.num_challenges = p.num_challenges; a.num_regs = c->num_regs; a.rc = ctx->d_rc;
-  launch_native_check(ctx->stream, a, (unsigned long long *)(d_small + SMALL_CHECK));
+  launch_native_check(ctx->stream, a, c->dev_gates, (unsigned long long *)(d_small + SMALL_CHECK));
   LCP2_HIP(ctx, hipGetLastError());
   u64 bad = 0;
   LCP2_TRY(download(ctx, &bad, d_small + SMALL_CHECK, 8));
@@ -237,7 +250,8 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
   const u32 ncs = p.num_constants + p.num_routed_wires, CH = p.num_challenges, npp = npp_of(p), nchunks = npp + 1;
   {  // the device runs the staged form of the programs (prover_kernels.hpp); the verifier keeps the caller's form
     static_assert(sizeof(GateDev) == sizeof(lcp2_gate), "GateDev mirrors lcp2_gate");
-    std::vector<GateDev> dev_gates(c->gates.size());
+    std::vector<GateDev> &dev_gates = c->dev_gates;
+    dev_gates.resize(c->gates.size());
     memcpy(dev_gates.data(), c->gates.data(), c->gates.size() * sizeof(lcp2_gate));
     std::vector<uint32_t> staged, lists;
     stage_gate_programs(c->code, dev_gates, p.num_wires, c->num_selectors, staged, lists);
@@ -559,8 +573,8 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     // the gate constraints on the n rows of H first (1/8 of the work below): a witness that violates one is the Err of prove()
     QuotientArgs h = a;
     h.wires = c->d_wires_cur; h.consts = c->cs_values.u(); h.leaf0 = 0; h.count = n; h.stride = n;
-    launch_gate_check(s, h, (unsigned long long *)(d_small + SMALL_CHECK));
-    launch_quotient(s, a);
+    launch_gate_check(s, h, c->dev_gates, (unsigned long long *)(d_small + SMALL_CHECK));
+    launch_quotient(s, a, c->dev_gates);
   }
   LCP2_HIP(ctx, hipGetLastError());
   u64 bad_row = ~0ull;

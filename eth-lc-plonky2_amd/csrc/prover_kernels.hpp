@@ -16,6 +16,7 @@ constexpr u32 QUOTIENT_MAX_CH = 2;
 // instead of one per operand (the interpreter executes one instruction at a time, so an operand load cannot overlap anything).
 constexpr u32 QUOTIENT_STAGE = 12;
 constexpr u32 QUOTIENT_ALPHA_POWS = 32; // >= CH + CH * PERM_MAX_CHUNKS + 1 exponents
+constexpr u32 QUOTIENT_GENERATED_GATES = 4;  // programs in csrc/generated_gates.hpp (static_assert-ed against the file)
 constexpr u32 QOP_LDG = 10;      // w0 = 10 | count << 8, w1 = offset into stage_list
 constexpr u32 QKIND_STAGE = 5;   // operand = staging slot idx
 constexpr u32 EVAL_CHUNK = 4096;
@@ -99,17 +100,17 @@ void launch_scan(hipStream_t s, bool mul, const u64 *in, u64 *out, u64 *block_to
 u64 scan_scratch_words(u64 n, u32 batches);
 void launch_perm_chunks(hipStream_t s, const PermArgs &a);
 void launch_perm_finalize(hipStream_t s, const PermArgs &a);
-void launch_quotient(hipStream_t s, const QuotientArgs &a);
+void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates);
 // host: rewrites validated gate programs into the staged device form (new code, per-gate offsets in `gates`, column lists)
 void stage_gate_programs(const std::vector<uint32_t> &code, std::vector<GateDev> &gates, u32 num_wires, u32 num_selectors,
                          std::vector<uint32_t> &staged_code, std::vector<uint32_t> &stage_list);
 // Row-wise check of the gate constraints over the n rows of H (the Err of prove() for an unsatisfiable witness): the same
 // gate programs on the witness VALUES (a.wires = witness [W][n], a.consts = constants values [NC][n], a.stride = a.count = n);
 // *flag (device, zeroed by the caller) receives 1 + the smallest row with a non-zero filtered constraint combination.
-void launch_gate_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag);
+void launch_gate_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag);
 // build()-time check of the LCP2_GATE_NATIVE_* claims: on a.count random points (a.wires / a.consts hold random field
 // elements) the native evaluators and the interpreted programs must give the same combination; *flag as in launch_gate_check
-void launch_native_check(hipStream_t s, const QuotientArgs &a, unsigned long long *flag);
+void launch_native_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag);
 void launch_eval_polys(hipStream_t s, const EvalArgs &a, u32 npolys, u64 *out);
 void launch_compose(hipStream_t s, const ComposeArgs &a);
 void launch_divide_finalize(hipStream_t s, const ComposeArgs &a, u64 *out0, u64 *out1);

@@ -99,6 +99,7 @@ void prog_public_input(Asm &a) {  // wires 0..4 against public_inputs_hash
   for (uint32_t i = 0; i < 4; i++) { a.begin(); a.sub(0, W(i), PI(i)); a.emit(R(0)); }
 }
 void prog_arithmetic(Asm &a) {
+  a.flags |= LCP2_GATE_NATIVE_ARITHMETIC;
   for (int k = 0; k < 20; k++) {
     a.begin();
     a.mul(0, W(4 * k), W(4 * k + 1));
@@ -161,7 +162,10 @@ void prog_poseidon(Asm &a) {
   }
   for (uint32_t i = 0; i < 12; i++) { a.sub(T, R(i), W(POS_WIRE_OUTPUT + i)); a.emit(R(T)); a.begin(); }
 }
+// The four SHA-256 gates have straight-line device forms generated from these very programs (tools/gen/run.sh ->
+// csrc/generated_gates.hpp, in this order); the flag is the claim, lcp2_circuit_create checks it.
 void prog_sha_add(Asm &a) {
+  a.flags |= LCP2_GATE_NATIVE_GENERATED(0);
   for (int j = 0; j < SHA_ADD_OPS; j++) {
     const uint32_t x = 3 * j, y = 3 * j + 1, out = 3 * j + 2, bits = 9 + 33 * j, carry = bits + 32;
     for (int i = 0; i < 32; i++) a.boolean(bits + i);
@@ -184,6 +188,7 @@ void carry_tail(Asm &a, uint32_t carry0, int ncarry) {
   a.emit(R(1));
 }
 void prog_sha_round_e(Asm &a) {
+  a.flags |= LCP2_GATE_NATIVE_GENERATED(2);
   const uint32_t e = 0, f = 1, g = 2, h = 3, d = 4, w = 5, e_new = 6, t1 = 7, be = 8, bf = 40, bg = 72, c0 = 104, c3 = 107;
   for (int i = 0; i < 32; i++) a.boolean(be + i);
   for (int i = 0; i < 32; i++) a.boolean(bf + i);
@@ -210,6 +215,7 @@ void prog_sha_round_e(Asm &a) {
   a.boolean(c3);
 }
 void prog_sha_round_a(Asm &a) {
+  a.flags |= LCP2_GATE_NATIVE_GENERATED(1);
   const uint32_t wa = 0, wb = 1, wc = 2, t1 = 3, a_new = 4, ba = 8, bb = 40, bc = 72, c0 = 104;
   for (int i = 0; i < 32; i++) a.boolean(ba + i);
   for (int i = 0; i < 32; i++) a.boolean(bb + i);
@@ -229,6 +235,7 @@ void prog_sha_round_a(Asm &a) {
   for (int k = 0; k < 2; k++) a.boolean(c0 + k);
 }
 void prog_sha_sched(Asm &a) {
+  a.flags |= LCP2_GATE_NATIVE_GENERATED(3);
   const uint32_t w2 = 0, w7 = 1, w15 = 2, w16 = 3, wt = 4, b2 = 8, b15 = 40, c0 = 104;
   for (int i = 0; i < 32; i++) a.boolean(b2 + i);
   for (int i = 0; i < 32; i++) a.boolean(b15 + i);

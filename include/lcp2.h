@@ -213,7 +213,11 @@ enum { LCP2_OP_ADD = 0, LCP2_OP_SUB = 1, LCP2_OP_MUL = 2, LCP2_OP_EMIT = 3, LCP2
  * lcp2_circuit_create: program and native evaluator must agree on random wire values, otherwise LCP2_E_INVALID.  The
  * verifier always interprets the program.  0 = none. */
 #define LCP2_GATE_NATIVE_MASK 0xFF00u
-#define LCP2_GATE_NATIVE_POSEIDON 0x0100u /* PoseidonGate, gates/poseidon.rs: 135 wires, 123 constraints, EMIT_FORWARD order */
+#define LCP2_GATE_NATIVE_POSEIDON 0x0100u   /* PoseidonGate, gates/poseidon.rs: 135 wires, 123 constraints, EMIT_FORWARD order */
+#define LCP2_GATE_NATIVE_ARITHMETIC 0x0200u /* ArithmeticGate { num_ops = num_constraints }: wires 4k..4k+3, constants 0 and 1 */
+#define LCP2_GATE_NATIVE_BASE_SUM2 0x0300u  /* BaseSumGate<2> { num_limbs = num_constraints - 1 }: wire 0 = sum, wires 1.. = bits */
+/* straight-line device forms generated offline from gate programs (tools/gen/, csrc/generated_gates.hpp): program k of that file */
+#define LCP2_GATE_NATIVE_GENERATED(k) (0x8000u | ((uint32_t)(k) << 8))
 typedef struct {
   uint32_t selector_index, selector_value, group_start, group_end;
   uint32_t code_offset, code_len; /* in instructions */
