@@ -13,7 +13,11 @@ HBM when the timed region starts and the proof produced in the last step is chec
 
 N > 1: one rank per GPU, every rank proves its own witness of the same circuit (BASELINE configs[4],
 independent light-client updates: "replicas", no data-path collective) -> weak scaling; the only
-collectives are the timing barrier and the max-reduce of the elapsed time.
+collectives are the timing barrier and the max-reduce of the elapsed time.  After that timed region the same
+ranks prove ONE proof together, sharded by LDE coset with the witness arriving column-sharded (BASELINE
+configs[3]; eth-lc-plonky2_amd/parallel.py::ShardedProver over RCCL: all-gathers of the witness, its
+coefficients and the quotient planes, sum all-reduces of caps and proof shares); its wall time is reported
+beside the headline value as `config.sharded_proof` (a side field: `value` stays the replica throughput).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing, K4a):
 algorithmic bytes per launch / HIP-event time per launch measured inside this run.  `cpu_baseline` is the
@@ -29,10 +33,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one wave64 instruction per 4 cycles per SIMD
-POSEIDON_VALU_INSTR = 8 * 1209 + 22 * 484 + 118  # census of the compiled permutation; SQ_INSTS_VALU measures 20 462
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a full-rate wave64 VALU instruction issues in 2 cycles, 2.4 GHz -> 78.6 T lane-instructions/s
+VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9
+CLOCK_HZ = 2.4e9
+CENSUS = os.path.join(ROOT, "profiles", "r02_poseidon_census.json")  # tools/poseidon_census.py: instructions per permutation by
+# issue class x the issue rate of each class measured alone (tools/ubench/int_rates -> profiles/r02_ubench_int_rates.txt)
+
+
+def valu_roofline(perms_per_s):
+    """Poseidon is integer-VALU bound.  Two honest denominators: the full-rate VALU peak of the guide (every instruction at 2
+    cycles: unreachable for this opcode mix, v_mad_u64_u32 and the carry ops issue at 4.2-4.4), and the opcode-weighted issue floor
+    (each class at the rate it reaches alone in the microbenchmark).  No fraction above 1 is printed: where the kernel's mixed
+    stream issues faster than the solo rates predict, the fraction is 1 and `floor_exceeded_by` carries the ratio."""
+    try:
+        c = json.load(open(CENSUS))
+        instr, floor_cycles = c["valu_instructions"], c["issue_floor_cycles_per_permutation_per_wave"]
+    except (OSError, KeyError, ValueError):
+        return {"permutations_per_s": perms_per_s}
+    lane_instr = perms_per_s * instr
+    floor_perms = 256 * 4 * 64 * CLOCK_HZ / floor_cycles  # every SIMD issuing back to back, 64 permutations per wave
+    ratio = perms_per_s / floor_perms
+    return {"permutations_per_s": perms_per_s, "valu_instructions_per_permutation": instr,
+            "achieved_lane_instr_per_s": lane_instr, "full_rate_peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
+            "frac_of_full_rate_peak": lane_instr / VALU_PEAK_LANE_INSTR,
+            "issue_floor_permutations_per_s": floor_perms, "frac_of_issue_floor": min(ratio, 1.0),
+            "floor_exceeded_by": ratio if ratio > 1.0 else None,
+            "cycles_per_valu_instruction_per_simd": 256 * 4 * 64 * CLOCK_HZ / lane_instr}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")  # k_hash_leaves is unchanged since that pass  # tools/pmc_traffic.py on the --pmc passes of this bench
 
 
 def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
@@ -74,6 +102,42 @@ def real_lc_step():
         return None
 
 
+def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps=3):
+    """BASELINE configs[3]: one proof of the same circuit sharded over the `world` GPUs by LDE coset.  Every rank brings only its
+    column shard of the witness (a slice of the resident tensor stands in for the column-sharded host upload)."""
+    import numpy as np
+    import torch
+    comm = m.parallel.TorchComm(dist, dev, ctx)
+    prover = m.parallel.ShardedProver(ctx, circ, rank, world, comm, constants_sigmas_ptr=cs_ptr, mem=m.MEM_DEVICE)
+    prover.finish_build()
+    n = 1 << circ.params.degree_bits
+    first, end = prover.column_shard()
+    shard_ptr = w_dev.data_ptr() + 8 * first * n
+    times = []
+    for it in range(reps + 1):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if it:  # the first proof warms RCCL's channels up
+            times.append(time.perf_counter() - t0)
+    tt = torch.tensor([min(times)], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = None
+    if rank == 0:
+        digest, cap = prover.data.digest()
+        m.CircuitData.verifier_only(circ, digest, cap).verify(proof, pis)  # raises if the assembled proof is not accepted
+        ok = True
+    prover.close()
+    n_words = 1 << (circ.params.degree_bits + circ.params.rate_bits)
+    return {"workload": "configs[3]: the same n=2^%d proof sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
+            "ms_per_proof": float(tt.item()) * 1e3, "world": world, "proof_verified": ok,
+            "exchange_bytes_received_per_rank": int(8 * (world - 1) / world * (2 * circ.params.num_wires * n + circ.params.num_challenges * n_words)),
+            "exchange": "RCCL all_gather_into_tensor (in place): witness values, witness coefficients, %d quotient planes; all_reduce(SUM) of 3 caps and the proof array" % circ.params.num_challenges}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +145,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--degree-bits", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="also run the sharded-proof side measurement with one rank "
+                    "(RCCL process group of size 1: exercises the N > 1 code path on a one-GPU box)")
     ap.add_argument("--cpu-sample-bits", type=int, default=14, help="log2 rows of the oracle's bounded sample")
     return ap.parse_args()
 
@@ -129,6 +195,12 @@ def cpu_baseline(sample_bits, degree_bits):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner when its first communicator comes
+    # up) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes out through a
+    # saved duplicate of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -137,8 +209,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > 1 or a.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream(dev)
@@ -151,7 +225,8 @@ def main():
     cs_dev = torch.from_numpy(circ.constants_sigmas.view(np.int64)).to(dev)
     torch.cuda.synchronize()
     data = m.CircuitData.build(ctx, circ, constants_sigmas_ptr=cs_dev.data_ptr(), mem=m.MEM_DEVICE)
-    del cs_dev
+    if world == 1 and not a.force_sharded:
+        del cs_dev  # N > 1 keeps it for the sharded circuit built after the timed region
     # each rank proves its own witness: the free cells of the padding row carry the (rank, update) tag
     m.circuit.tag_witness(wires, rank + 1)
     w_dev = torch.from_numpy(wires.view(np.int64)).to(dev)
@@ -188,6 +263,11 @@ def main():
     prof_all = ctx.prof_get()
     prof = {k: {f: prof_all[k][f] - prof0[k][f] for f in ("ms", "launches", "bytes")} for k in prof_all}
     data.verify(proof, pis)  # raises if the GPU proof is not accepted
+    sharded = None
+    if (world > 1 or a.force_sharded) and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
+        data.close()  # the replica's 92 GB workspace makes room for the sharded handle
+        torch.cuda.empty_cache()
+        sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -217,18 +297,18 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves", lh["bytes"] / max(lh["launches"], 1)),
                          "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
                          "note": "integer-VALU bound (Poseidon), so the HBM fraction is legitimately low: see `valu` and DESIGN.md section 3",
-                         "valu": {"permutations_per_s": perms_per_s, "valu_instructions_per_permutation": POSEIDON_VALU_INSTR,
-                                  "achieved_lane_instr_per_s": perms_per_s * POSEIDON_VALU_INSTR, "peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
-                                  "frac": perms_per_s * POSEIDON_VALU_INSTR / VALU_PEAK_LANE_INSTR}},
+                         "valu": valu_roofline(perms_per_s)},
             "kernels": kern,
         }
+        if sharded:
+            out["config"]["sharded_proof"] = sharded
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample_bits, a.degree_bits), a.degree_bits)
             step_633 = real_lc_step()
             if step_633:
                 out["config"]["real_lc_step"] = step_633
-        print(json.dumps(out))
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or a.force_sharded:
         dist.destroy_process_group()
 
 

@@ -118,6 +118,7 @@ def load_library():
         "lcp2_proof_words": (c.c_size_t, [c.POINTER(Params)]),
         "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]),
         "lcp2_commit_wires": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]),
+        "lcp2_commit_wires_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_fri_open": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
@@ -308,7 +309,15 @@ class Context:
         o.block_first, o.block_count = block_first, block_count
         return o
 
-    # ---- timing
+    # ---- device buffers
+    def buffer_alloc(self, words):
+        p = ctypes.c_void_p()
+        self._check(self.lib.lcp2_buffer_alloc(self.handle, int(words) * 8, ctypes.byref(p)))
+        return p.value
+
+    def buffer_free(self, dev_ptr):
+        self._check(self.lib.lcp2_buffer_free(self.handle, ctypes.c_void_p(dev_ptr)))
+
     def buffer_read(self, dev_ptr, words):
         out = np.zeros(words, dtype=np.uint64)
         self._check(self.lib.lcp2_buffer_read(self.handle, _ptr(out), ctypes.c_void_p(dev_ptr), words * 8))
@@ -321,6 +330,7 @@ class Context:
     def buffer_copy(self, dst_ptr, src_ptr, words):
         self._check(self.lib.lcp2_buffer_copy(self.handle, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), words * 8))
 
+    # ---- timing
     def prof_enable(self, on=True):
         self._check(self.lib.lcp2_prof_enable(self.handle, int(on)))
 
@@ -489,6 +499,12 @@ class CircuitData:
         else:
             wp = ctypes.c_void_p(wires)
         self._check(self.lib.lcp2_commit_wires(self.handle, wp, mem, _ptr(cap)))
+        return cap
+
+    def commit_wires_coeffs(self, wires_ptr, coeffs_ptr):
+        """commit_wires with the coefficients supplied (device pointers): the sharded proof's polynomial-parallel iNTT"""
+        cap = self._cap()
+        self._check(self.lib.lcp2_commit_wires_coeffs(self.handle, ctypes.c_void_p(wires_ptr), ctypes.c_void_p(coeffs_ptr), _ptr(cap)))
         return cap
 
     def perm_zs(self, betas, gammas):

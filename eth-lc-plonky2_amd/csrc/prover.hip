@@ -471,8 +471,9 @@ namespace {
     NttHost<DeviceNttBackend> ntt(be); \
     (void)N; (void)lgN; (void)W; (void)NR; (void)NC; (void)CH; (void)Q; (void)npp; (void)nchunks; (void)ncs; (void)L; (void)s; (void)ntt;
 
-// PolynomialBatch::from_values on the witness (K1-K4)
-int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, u64 *cap_out) {
+// PolynomialBatch::from_values on the witness (K1-K4).  d_coeffs (nullable, device): the coefficients of every wire column,
+// already computed (a sharded proof runs the iNTT polynomial-parallel across the ranks and all-gathers the result).
+int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const u64 *d_coeffs, u64 *cap_out) {
   LCP2_STAGE_PROLOGUE
   const u64 *d_wires = wires_in;
   if (wires_mem == LCP2_MEM_HOST) {
@@ -481,7 +482,8 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, u64 *c
     d_wires = c->wires_vals.u();
   }
   c->stage = lcp2_circuit::ST_NONE;
-  LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
+  if (d_coeffs) LCP2_TRY(commit_coeffs_dev(ctx, d_coeffs, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, true));
+  else LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
   LCP2_TRY(download_cap(c, c->wires, cap_out));
   c->d_wires_cur = d_wires;
   c->stage = lcp2_circuit::ST_WIRES;
@@ -834,7 +836,7 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   u64 pi_hash[4];
   H.hash_no_pad(pis.data(), c->npi, pi_hash);
 
-  LCP2_TRY(stage_wires(c, (const u64 *)wires_in_, wires_mem, proof + L.wires_cap));
+  LCP2_TRY(stage_wires(c, (const u64 *)wires_in_, wires_mem, nullptr, proof + L.wires_cap));
   HostChallenger ch;
   ch.observe_n(c->digest, 4);
   ch.observe_n(pi_hash, 4);
@@ -868,7 +870,12 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
 extern "C" int lcp2_commit_wires(lcp2_circuit *c, const uint64_t *wires, lcp2_mem mem, uint64_t *cap) {
   if (!c || !wires || !cap) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  return stage_wires(c, (const u64 *)wires, mem, (u64 *)cap);
+  return stage_wires(c, (const u64 *)wires, mem, nullptr, (u64 *)cap);
+}
+extern "C" int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, const uint64_t *coeffs, uint64_t *cap) {
+  if (!c || !wires || !coeffs || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_wires(c, (const u64 *)wires, LCP2_MEM_DEVICE, (const u64 *)coeffs, (u64 *)cap);
 }
 extern "C" int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap) {
   if (!c || !betas || !gammas || !cap) return LCP2_E_INVALID;

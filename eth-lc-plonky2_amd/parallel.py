@@ -12,6 +12,8 @@ every block is two whole cap subtrees, so the commitment (the cap) is bit-identi
 The compute steps are passed in as callables so that the same orchestration runs on RCCL with the HIP kernels
 (`gpu_ops`) and on gloo with the oracle in the CPU tests.
 """
+import ctypes
+
 import numpy as np
 
 
@@ -102,36 +104,81 @@ class GpuOps:
 # ---------------------------------------------------------------------------------------------------------------------
 # One whole proof sharded by LDE coset (include/lcp2.h "one proof sharded over the GPUs of a node").
 class ShardedProver:
-    """Rank `rank` of `world` in a coset-sharded proof.  Every rank holds the whole witness and runs the same sequence of
-    seams on its own leaf blocks; results are shares that a SUM all-reduce assembles (caps, the proof array; uint64 wrap-around,
-    the shares are disjoint) plus one bulk all-reduce of the quotient values.  `comm` supplies the two collectives:
-        comm.sum_host(numpy uint64 array) -> numpy uint64 array      (tiny: 512-byte caps, the proof array)
-        comm.sum_device(device pointer, uint64 words)                 (in place; 2 * 8n words: RCCL over xGMI)
-    so that the same orchestration runs over torch.distributed (TorchComm) and, in the single-GPU tests, over ranks that are
-    stepped in lockstep inside one process."""
+    """Rank `rank` of `world` in a coset-sharded proof: the rank holds 8 / world leaf blocks of every LDE and Merkle tree and
+    runs the seams of data.prove() on them.  What crosses the ranks:
+        witness        column-sharded arrival (prove_steps(..., sharded_columns=True)): every rank uploads only its column
+                       shard, the values are all-gathered over xGMI, every rank transforms its own columns (polynomial-parallel
+                       iNTT) and the coefficients are all-gathered: the commitment's "column transpose" 
+        caps, proof    shares (own entries at their global position, zeros elsewhere): SUM all-reduce of 512-byte caps and of
+                       the 140 KB proof array (uint64 wrap-around; RCCL has no bitwise reductions)
+        quotient       each challenge plane of the value buffer is completed by an in-place all-gather of the ranks' contiguous
+                       leaf blocks (537 MB in total at n = 2^22, each byte crosses the fabric once)
+    `comm` supplies the collectives, so that the same orchestration runs over torch.distributed (TorchComm: "nccl" = RCCL on
+    the node, "gloo" in the CPU tests) and, in the single-GPU tests, over ranks stepped in lockstep inside one process:
+        comm.sum_host(numpy uint64 array) -> numpy uint64 array
+        comm.all_gather_device(device pointer, total words, words per rank)    in place: rank r's part sits at r * words per rank"""
 
     def __init__(self, ctx, circ, rank, world, comm, constants_sigmas_ptr=None, mem=0):
         from . import binding as b
-        self.b, self.circ, self.rank, self.world, self.comm = b, circ, rank, world, comm
+        self.b, self.ctx, self.circ, self.rank, self.world, self.comm = b, ctx, circ, rank, world, comm
         first, count = block_range(rank, world, circ.params.rate_bits)
         self.data = b.CircuitData.build_sharded(ctx, circ, first, count, constants_sigmas_ptr, mem)
         self.cap_share = self.data.digest()[1]
+        self._vals = self._coeffs = None
 
     def finish_build(self):
         self.data.set_constants_cap(self.comm.sum_host(self.cap_share))
         self.digest = self.data.digest()[0]
 
+    def column_shard(self):
+        """(first, end) of the witness columns this rank brings in the column-sharded arrival"""
+        return column_shards(self.circ.params.num_wires, self.world)[self.rank]
+
+    def _witness_buffers(self, most):
+        n = 1 << self.circ.params.degree_bits
+        words = self.world * most * n
+        if self._vals is None:
+            self._vals, self._coeffs = self.ctx.buffer_alloc(words), self.ctx.buffer_alloc(words)
+        return self._vals, self._coeffs
+
     # the proof as a generator of exchange points, so that a test can interleave several ranks in one process
-    def prove_steps(self, wires, public_inputs, mem=0):
-        b, d, p = self.b, self.data, self.circ.params
+    def prove_steps(self, wires, public_inputs, mem=0, sharded_columns=False):
+        """wires: the whole witness [num_wires][n] (numpy, or a device pointer with mem=MEM_DEVICE); with sharded_columns=True
+        only this rank's columns [column_shard()][n]."""
+        b, d, p, ctx = self.b, self.data, self.circ.params, self.ctx
         capw = 4 << p.cap_height
+        n = 1 << p.degree_bits
         proof = np.zeros(d.proof_words, dtype=np.uint64)
         pis = np.asarray(public_inputs, dtype=np.uint64)
         ch = b.Challenger()
         ch.observe(self.digest)
         pi_hash = b.hash_no_pad(pis)
         ch.observe(pi_hash)
-        share = d.commit_wires(wires, mem)
+        if sharded_columns:
+            shards = column_shards(p.num_wires, self.world)
+            most = max(e - s for s, e in shards)
+            first, end = shards[self.rank]
+            vals, coeffs = self._witness_buffers(most)
+            mine = self.rank * most * n  # word offset of this rank's slot
+            if mem == b.MEM_HOST:
+                ctx.buffer_write(vals + 8 * mine, np.ascontiguousarray(wires, dtype=np.uint64).reshape(end - first, n))
+            else:
+                ctx.buffer_copy(vals + 8 * mine, wires, (end - first) * n)
+            yield ("all_gather_device", vals, self.world * most * n, most * n)
+            # polynomial-parallel iNTT: own columns only, then the coefficient all-gather
+            ctx.buffer_copy(coeffs + 8 * mine, vals + 8 * mine, (end - first) * n)
+            if end > first:
+                ctx._check(ctx.lib.lcp2_ntt_batch(ctx.handle, ctypes.c_void_p(coeffs + 8 * mine), end - first, p.degree_bits, 1, 1, b.MEM_DEVICE))
+            yield ("all_gather_device", coeffs, self.world * most * n, most * n)
+            if any(e - s != most for s, e in shards[:-1]):  # a short shard in the middle: close the gaps (both buffers alike)
+                for buf in (vals, coeffs):               # column by column, in increasing order: source and destination never overlap
+                    for r, (s0, e0) in enumerate(shards):
+                        for col in range(e0 - s0):
+                            if r * most != s0:
+                                ctx.buffer_copy(buf + 8 * (s0 + col) * n, buf + 8 * (r * most + col) * n, n)
+            share = d.commit_wires_coeffs(vals, coeffs)
+        else:
+            share = d.commit_wires(wires, mem)
         proof[0:capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[0:capw])
         betas, gammas = ch.get(p.num_challenges), ch.get(p.num_challenges)
@@ -140,7 +187,10 @@ class ShardedProver:
         ch.observe(proof[capw:2 * capw])
         alphas = ch.get(p.num_challenges)
         d.quotient_values(alphas, pi_hash)
-        yield ("sum_device",) + d.quotient_buffer()
+        qptr, qwords = d.quotient_buffer()
+        plane = qwords // p.num_challenges  # 8n words per challenge; this rank's blocks are one contiguous run of it
+        for c in range(p.num_challenges):
+            yield ("all_gather_device", qptr + 8 * c * plane, plane, plane // self.world)
         share = d.quotient_commit()
         proof[2 * capw:3 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[2 * capw:3 * capw])
@@ -153,8 +203,8 @@ class ShardedProver:
         self.proof = proof
         return
 
-    def prove(self, wires, public_inputs, mem=0):
-        steps = self.prove_steps(wires, public_inputs, mem)
+    def prove(self, wires, public_inputs, mem=0, sharded_columns=False):
+        steps = self.prove_steps(wires, public_inputs, mem, sharded_columns)
         reply = None
         try:
             while True:
@@ -162,10 +212,24 @@ class ShardedProver:
                 if req[0] == "sum_host":
                     reply = self.comm.sum_host(req[1])
                 else:
-                    self.comm.sum_device(req[1], req[2])
+                    self.comm.all_gather_device(req[1], req[2], req[3])
                     reply = None
         except StopIteration:
             return self.proof
+
+    def close(self):
+        for buf in (self._vals, self._coeffs):
+            if buf:
+                self.ctx.buffer_free(buf)
+        self._vals = self._coeffs = None
+        self.data.close()
+
+
+class _DevicePtr:
+    """zero-copy view of a raw device allocation for torch.as_tensor (CUDA array interface v2)"""
+
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (int(words),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
 class TorchComm:
@@ -182,10 +246,19 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # two's-complement wrap-around = uint64 addition
         return t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
 
-    def sum_device(self, ptr, words):
+    def all_gather_tensor(self, out, rank):
+        """in-place all-gather on a 1-D tensor: rank r's part is out[r * k : (r + 1) * k] (RCCL recognises the aliasing and
+        moves every byte once; gloo gets a private copy of the input)"""
+        k = out.numel() // self.dist.get_world_size()
+        mine = out[rank * k:(rank + 1) * k]
+        if self.dist.get_backend() != "nccl":
+            mine = mine.clone()
+        self.dist.all_gather_into_tensor(out, mine)
+
+    def all_gather_device(self, ptr, total_words, words_per_rank):
         import torch
-        t = torch.empty(words, dtype=torch.int64, device=self.device)  # staging tensor: two device copies (< 1 ms at 537 MB)
-        self.ctx.buffer_copy(t.data_ptr(), ptr, words)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        self.ctx.buffer_copy(ptr, t.data_ptr(), words)
+        assert total_words == words_per_rank * self.dist.get_world_size()
+        self.ctx.sync()  # the library's stream has written this rank's part
+        out = torch.as_tensor(_DevicePtr(ptr, total_words), device=self.device)  # aliases the library's buffer: no staging copies
+        self.all_gather_tensor(out, self.dist.get_rank())
+        torch.cuda.synchronize(self.device)

@@ -303,16 +303,24 @@ int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* 
  * seams above; what a rank returns is its SHARE of the result - its own cap entries / query answers at their global
  * position, zeros elsewhere; the parts of lcp2_fri_open's output that every rank computes identically come from the rank
  * holding block 0 only - so one SUM all-reduce (uint64 wrap-around; RCCL has no bitwise reductions) of each cap and of
- * the proof words lcp2_fri_open wrote assembles the result.  The only bulk exchange is the quotient values
- * (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer (zeros elsewhere), the caller
- * sum-all-reduces that buffer in place over RCCL, then every rank calls lcp2_quotient_commit.  Order per proof:
- *   lcp2_commit_wires -> sum caps -> lcp2_perm_zs -> sum caps -> lcp2_quotient_values -> all-reduce buffer ->
+ * the proof words lcp2_fri_open wrote assembles the result.  The bulk exchanges are (1) the witness: the ranks may hold
+ * column shards, all-gather the values, transform their own columns and all-gather the coefficients (lcp2_commit_wires_coeffs);
+ * (2) the quotient values (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer - per challenge
+ * plane they are one contiguous run at offset block_first * n, in rank order - so an in-place all-gather of each plane
+ * completes the buffer (a SUM all-reduce works too: the rest is zeros); then every rank calls lcp2_quotient_commit.
+ * Order per proof:
+ *   lcp2_commit_wires[_coeffs] -> sum caps -> lcp2_perm_zs -> sum caps -> lcp2_quotient_values -> all-gather planes ->
  *   lcp2_quotient_commit -> sum caps -> lcp2_fri_open -> sum the words from the openings on.
  * At build: lcp2_circuit_create_sharded, lcp2_circuit_digest (cap share; digest not valid yet), sum the cap,
  * lcp2_circuit_set_constants_cap.  lcp2_prove / lcp2_quotient refuse a sharded circuit. */
 int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, uint32_t block_first, uint32_t block_count,
                                 lcp2_circuit **out);
 int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap);
+/* lcp2_commit_wires with the iNTT already done: `wires` = witness values, `coeffs` = their coefficients, both device, column-major
+ * [num_wires][n].  A sharded proof runs the iNTT polynomial-parallel (rank g transforms its column shard with lcp2_ntt_batch)
+ * and all-gathers the coefficients over RCCL (the "column transpose" of the commitment); the values are still needed
+ * for the permutation argument and the LCP2_E_UNSAT check.  The coefficients are copied into the circuit's oracle. */
+int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, const uint64_t *coeffs, uint64_t *cap);
 int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4]);
 int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words);
 int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap);

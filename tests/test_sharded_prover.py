@@ -24,23 +24,26 @@ class LockstepComm:
             acc += a  # uint64 wrap-around, as the int64 SUM all-reduce does
         return acc
 
-    def sum_device_all(self, bufs):
-        acc = None
-        for ptr, words in bufs:
-            v = self.ctx.buffer_read(ptr, words)
-            acc = v if acc is None else acc + v
-        for ptr, words in bufs:
-            self.ctx.buffer_write(ptr, acc)
+    def all_gather_device_all(self, reqs):
+        """reqs[r] = (pointer, total words, words per rank) of rank r: every buffer ends up with every rank's part"""
+        parts = [self.ctx.buffer_read(ptr + 8 * r * wpr, wpr) for r, (ptr, total, wpr) in enumerate(reqs)]
+        for ptr, total, wpr in reqs:
+            assert total == wpr * len(reqs)
+            for r, part in enumerate(parts):
+                self.ctx.buffer_write(ptr + 8 * r * wpr, part)
 
 
-def _run_lockstep(m, ctx, circ, wires, pis, world):
+def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False):
     comm = LockstepComm(ctx)
     ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
     cap = comm.sum_host_all([r.cap_share for r in ranks])
     for r in ranks:
         r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
         r.finish_build()
-    gens = [r.prove_steps(wires, pis) for r in ranks]
+    if sharded_columns:  # every rank brings only its column shard of the witness
+        gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True) for r in ranks]
+    else:
+        gens = [r.prove_steps(wires, pis) for r in ranks]
     replies = [None] * world
     while True:
         reqs = []
@@ -56,20 +59,22 @@ def _run_lockstep(m, ctx, circ, wires, pis, world):
             merged = comm.sum_host_all([q[1] for q in reqs])
             replies = [merged.copy() for _ in range(world)]
         else:
-            comm.sum_device_all([(q[1], q[2]) for q in reqs])
+            comm.all_gather_device_all([(q[1], q[2], q[3]) for q in reqs])
             replies = [None] * world
     return ranks
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,degree_bits", [(2, 9), (4, 8), (8, 10), (8, 5)])
-def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits):
+@pytest.mark.parametrize("world,degree_bits,sharded_columns", [(2, 9, False), (4, 8, True), (8, 10, True), (8, 5, False), (2, 6, True), (8, 6, True)])
+def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits, sharded_columns):
+    """sharded_columns: the witness arrives column-sharded, is all-gathered, transformed polynomial-parallel and the
+    coefficients all-gathered (135 columns over 8 ranks: shards of 17 and one of 16; over 2 and 4: 68/67 and 34/34/34/33)"""
     import eth_lc_plonky2_amd as m
     params = m.standard_params(degree_bits, 4)
     circ, wires, pis = m.circuit.synthetic_circuit(params, seed=900 + world)
     single = m.CircuitData.build(gpu_ctx, circ)
     want = single.prove(wires, pis)
-    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, world)
+    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, world, sharded_columns)
     for r in ranks:
         assert (r.digest == single.digest()[0]).all()
         bad = np.nonzero(r.proof != want)[0]
@@ -79,8 +84,41 @@ def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits):
     with pytest.raises(m.Lcp2Error):
         ranks[0].data.prove(wires, pis)  # a sharded handle refuses the monolithic call
     for r in ranks:
-        r.data.close()
+        r.close()
     single.close()
+
+
+@pytest.mark.gpu
+def test_sharded_columns_with_a_short_middle_shard(gpu_ctx):
+    """130 wires over 8 ranks: shards 17, 17, 16 x 6: the padded all-gather layout has gaps that are closed before the commitment"""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import poseidon_py  # noqa: F401
+    params = m.standard_params(7, 4)
+    params.num_wires = 140
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=31)
+    assert [e - s for s, e in m.parallel.column_shards(140, 8)] == [18, 18, 18, 18, 17, 17, 17, 17]
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, 8, True)
+    assert (ranks[3].proof == want).all()
+    for r in ranks:
+        r.close()
+    single.close()
+
+
+@pytest.mark.gpu
+def test_device_pointer_view_aliases_library_memory(gpu_ctx):
+    """TorchComm.all_gather_device hands RCCL a tensor that IS the library's buffer (CUDA array interface, no staging copy)"""
+    import torch
+    import eth_lc_plonky2_amd as m
+    p = gpu_ctx.buffer_alloc(1024)
+    gpu_ctx.buffer_write(p, np.arange(1024, dtype=np.uint64))
+    t = torch.as_tensor(m.parallel._DevicePtr(p, 1024), device=torch.device("cuda", 0))
+    assert t.dtype == torch.int64 and t.data_ptr() == p and int(t[1000].item()) == 1000
+    t[7] = -1
+    torch.cuda.synchronize()
+    assert int(gpu_ctx.buffer_read(p, 8)[7]) == 2 ** 64 - 1
+    gpu_ctx.buffer_free(p)
 
 
 def test_host_transcript_helpers_match_oracle(oracle):
@@ -152,7 +190,7 @@ assert m.parallel.block_range(rank, 2) == (4 * rank, 4)
 # ShardedProver.prove() end to end over real gloo collectives, with the per-rank compute replaced by a stand-in that returns
 # disjoint shares the way the C ABI does (own entries at their global position, zeros elsewhere; replicated words from rank 0)
 class FakeParams:
-    cap_height, num_challenges, rate_bits = 4, 2, 3
+    cap_height, num_challenges, rate_bits, degree_bits, num_wires = 4, 2, 3, 2, 135
 class FakeCirc:
     params = FakeParams()
 class FakeData:
@@ -164,21 +202,24 @@ class FakeData:
         return c
     def commit_wires(self, wires, mem): return self._share(1)
     def perm_zs(self, betas, gammas): self.seen = [int(betas[0]), int(gammas[1])]; return self._share(2)
-    def quotient_values(self, alphas, pis): self.qbuf[32 * self.rank:32 * self.rank + 32] = np.arange(32, dtype=np.uint64) + np.uint64(int(alphas[0]) % 1000)
-    def quotient_buffer(self): return (id(self.qbuf), self.qbuf.size)
+    def quotient_values(self, alphas, pi_hash):  # this rank's blocks of both challenge planes (32 words each), zeros elsewhere
+        for c in range(2):
+            self.qbuf[32 * c + 16 * self.rank:32 * c + 16 * self.rank + 16] = np.arange(16, dtype=np.uint64) + np.uint64(int(alphas[0]) % 1000 + 50 * c)
+    def quotient_buffer(self): return (self.qbuf.ctypes.data, self.qbuf.size)
     def quotient_commit(self): return self._share(3 + int(self.qbuf.sum() % 5))  # depends on the exchanged buffer
     def fri_open(self, zeta, state, proof):
         body = proof[3 * 64:]
         if self.rank == 0: body[:20] = np.arange(20, dtype=np.uint64) + np.uint64(int(zeta[0]) % 97)   # replicated part
         body[20 + 10 * self.rank:30 + 10 * self.rank] = np.uint64(555 + self.rank)                     # this rank's query answers
 class GlooComm(m.parallel.TorchComm):
-    def sum_device(self, ptr, words):  # the "device" buffer of the stand-in is a numpy array
-        buf = bufs[ptr]
-        buf[:] = self.sum_host(buf)
+    def all_gather_device(self, ptr, total_words, words_per_rank):  # the "device" buffer of the stand-in is a numpy array
+        import torch
+        off = (ptr - sp.data.qbuf.ctypes.data) // 8
+        view = torch.from_numpy(sp.data.qbuf.view(np.int64))[off:off + total_words]
+        self.all_gather_tensor(view, rank)
 sp = object.__new__(m.parallel.ShardedProver)
-sp.b, sp.circ, sp.rank, sp.world, sp.comm = m.binding, FakeCirc(), rank, 2, GlooComm(dist)
+sp.b, sp.ctx, sp.circ, sp.rank, sp.world, sp.comm = m.binding, None, FakeCirc(), rank, 2, GlooComm(dist)
 sp.data = FakeData(rank)
-bufs = {id(sp.data.qbuf): sp.data.qbuf}
 sp.digest = np.arange(4, dtype=np.uint64)
 proof = sp.prove(None, np.array([3, 4], dtype=np.uint64))
 # both ranks hold the same assembled proof: caps complete, quotient buffer complete, replicated words once, every query answered
@@ -187,6 +228,16 @@ dist.all_gather_object(gathered, proof.tobytes())
 assert gathered[0] == gathered[1]
 caps = proof[:192].reshape(3, 16, 4)
 assert (caps[0] != 0).all() and (caps[1][8:] != 0).all() and (sp.data.qbuf != 0).sum() >= 62
+# the two planes of the quotient buffer were completed by in-place all-gathers of the ranks' contiguous runs
+a0 = int(sp.data.qbuf[0])
+want_q = np.concatenate([np.arange(16, dtype=np.uint64) + np.uint64(a0 + 50 * c) for c in range(2) for r in range(2)])
+assert (sp.data.qbuf == want_q).all()
+# and the in-place all-gather primitive on its own
+import torch
+t = torch.zeros(8, dtype=torch.int64)
+t[4 * rank:4 * rank + 4] = torch.arange(4) + 10 * (rank + 1)
+sp.comm.all_gather_tensor(t, rank)
+assert t.tolist() == [10, 11, 12, 13, 20, 21, 22, 23]
 body = proof[192:]
 assert (body[20:30] == 555).all() and (body[30:40] == 556).all() and body[1] == body[0] + 1
 dist.destroy_process_group()
