@@ -1,7 +1,9 @@
 // The reference's main() (eth-lc-plonky2/src/main.rs:30-233) on this backend: two consecutive light-client updates in,
 // one proof of the contract-state transition out.  The RPC fetch of main.rs:33-56 is replaced by two files (the beacon
 // API V1_5 layout or the layout of the reference's fixture files); the recursive BLS verifier is stubbed.
-//   lc_prover <prev_update.json> <cur_update.json> [--witness-only] [--device N] [--repeat K]
+//   lc_prover <prev_update.json> <cur_update.json> [--witness-only] [--device N] [--repeat K] [--extra-committees C]
+// --extra-committees C adds C more SyncCommitteeSSZ gadgets (1 025 two_to_one_sha256 = 317 750 rows each) on the update's own
+// committee: with C = 6 the circuit has 7 x 1 025 + 32 hashes and 2^22 rows, the reference's scale, made of real gadgets.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,11 +35,12 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 int main(int argc, char **argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s <prev_update.json> <cur_update.json> [--witness-only] [--device N] [--repeat K]\n", argv[0]); return 2; }
   bool witness_only = false;
-  int device = 0, repeat = 1;
+  int device = 0, repeat = 1, extra = 0;
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "--witness-only")) witness_only = true;
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--extra-committees") && i + 1 < argc) extra = atoi(argv[++i]);
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -51,11 +54,22 @@ int main(int argc, char **argv) {
     ProofTarget target = add_virtual_proof_target(builder);
     for (auto &limb : target.cur_state) builder.register_public_input(limb.t);  // src/main.rs:180-187
     for (auto &limb : target.new_state) builder.register_public_input(limb.t);
+    std::vector<SyncCommitteeTarget> more;
+    for (int k = 0; k < extra; k++) {
+      more.push_back(add_virtual_sync_committee_target(builder));
+      ssz_sync_committee(builder, more.back());
+    }
+    const size_t gates = builder.num_gates();
     auto data = builder.build();
-    printf("circuit built in %.1f ms: degree_bits %u\n", ms_since(t0), data->degree_bits());
+    printf("circuit built in %.1f ms: %zu gates, degree_bits %u\n", ms_since(t0), gates, data->degree_bits());
 
     PartialWitness pw;
     const LightClientStep st = set_light_client_step(pw, target, prev, cur, NetworkConfig::mainnet());
+    for (const SyncCommitteeTarget &sc : more) {  // the extra trees hash the signing committee again
+      for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++)
+        pw.set_target_arr(sc.pubkeys[i], std::vector<F>(prev.next_sync_committee.pubkeys[i].begin(), prev.next_sync_committee.pubkeys[i].end()));
+      pw.set_target_arr(sc.aggregate_pubkey, std::vector<F>(prev.next_sync_committee.aggregate_pubkey.begin(), prev.next_sync_committee.aggregate_pubkey.end()));
+    }
     printf("cur_state %s\nnew_state %s\nsigning_root %s\nparticipation %zu/512, attested from next period: %s\n", hex(st.cur_state).c_str(),
            hex(st.new_state).c_str(), hex(st.signing_root).c_str(), st.participation, st.is_attested_from_next_period ? "yes" : "no");
 
