@@ -264,7 +264,10 @@ def main():
     if (world > 1 or a.force_sharded) and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
         data.close()  # the replica's 92 GB workspace makes room for the sharded handle
         torch.cuda.empty_cache()
-        sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
+        try:
+            sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
+        except Exception as e:  # a side measurement must never take the bench line down
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3

@@ -133,6 +133,10 @@ def load_library():
         "lcp2_quotient_commit": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_verify": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.POINTER(c.c_int)]),
         "lcp2_last_challenges": (c.c_int, [c.c_void_p, c.c_void_p]),
+        "lcp2_proof_bytes": (c.c_size_t, [c.POINTER(Params), c.c_size_t, c.c_uint32]),
+        "lcp2_proof_to_bytes": (c.c_int, [c.POINTER(Params), c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_size_t]),
+        "lcp2_proof_from_bytes": (c.c_int, [c.POINTER(Params), c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]),
+        "lcp2_verifier_data_to_bytes": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_prof_enable": (c.c_int, [c.c_void_p, c.c_int]),
         "lcp2_prof_reset": (c.c_int, [c.c_void_p]),
         "lcp2_prof_get": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_uint64), c.POINTER(c.c_double)]),
@@ -380,6 +384,32 @@ def hash_no_pad(values):
     return out
 
 
+SER_PUBLIC_INPUT_COUNT = 1
+
+
+def proof_to_bytes(params, proof, public_inputs, flags=SER_PUBLIC_INPUT_COUNT):
+    """ProofWithPublicInputs::to_bytes (plonky2 util/serialization.rs layout, see include/lcp2.h; parity unpinned)"""
+    lib = load_library()
+    pr, pis = _np_u64(proof).ravel(), _np_u64(public_inputs).ravel()
+    out = np.zeros(lib.lcp2_proof_bytes(ctypes.byref(params), pis.size, flags), dtype=np.uint8)
+    rc = lib.lcp2_proof_to_bytes(ctypes.byref(params), _ptr(pr), pr.size, _ptr(pis), pis.size, flags, _ptr(out), out.size)
+    if rc:
+        raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+    return out.tobytes()
+
+
+def proof_from_bytes(params, data, num_public_inputs, flags=SER_PUBLIC_INPUT_COUNT):
+    """-> (proof words, public inputs); Lcp2Error on a malformed buffer"""
+    lib = load_library()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    proof = np.zeros(lib.lcp2_proof_words(ctypes.byref(params)), dtype=np.uint64)
+    pis = np.zeros(num_public_inputs, dtype=np.uint64)
+    rc = lib.lcp2_proof_from_bytes(ctypes.byref(params), _ptr(buf) if buf.size else None, buf.size, flags, _ptr(proof), proof.size, _ptr(pis), pis.size)
+    if rc:
+        raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+    return proof, pis
+
+
 class ProofRejected(Lcp2Error):
     """data.verify(proof) failed; .check names the failed step (see lcp2_verify)."""
 
@@ -534,6 +564,12 @@ class CircuitData:
         if rc == -7:
             raise ProofRejected(failed.value)
         self._check(rc)
+
+    def verifier_data_bytes(self):
+        """VerifierOnlyCircuitData::to_bytes: constants_sigmas_cap then circuit_digest"""
+        out = np.zeros(((4 << self.circ.params.cap_height) + 4) * 8, dtype=np.uint8)
+        self._check(self.lib.lcp2_verifier_data_to_bytes(self.handle, _ptr(out), out.size))
+        return out.tobytes()
 
     def last_challenges(self):
         out = np.zeros(97, dtype=np.uint64)

@@ -298,19 +298,22 @@ __device__ u64 q_sbox(u64 x);
 // 1..3 at 29 + 12 (r - 1) + i, of the partial rounds at 65 + r, of full rounds 4..7 at 87 + 12 r + i.  The constraints come out
 // first to last; acc is the Horner chain with 1 / alpha (rescaled by the caller), as for every EMIT_FORWARD gate.
 #if defined(__HIP_DEVICE_COMPILE__)
+// The running combination of a gate's constraints.  acc is kept LAZY (any u64 congruent to the value): a Horner step is a
+// 17-instruction multiply-reduce plus a 3-instruction add of the canonical constraint value, instead of 21 + 8 for canonical
+// arithmetic; whoever reads acc multiplies it with gl_mul, which accepts any u64 and returns a canonical value.
 struct QEmit {
   u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
   u32 CH, emitted;
   __device__ __forceinline__ void operator()(u64 x) {  // forward gates: Horner with 1 / alpha (step = 0 encodes alpha = 0)
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) acc[c] = step[c] == 0 ? (emitted ? acc[c] : x) : gl_add(gl_mul(acc[c], step[c]), x);
+      if (c < CH) acc[c] = step[c] == 0 ? (emitted ? acc[c] : x) : gl_add_nc(gl_mul_nc(acc[c], step[c]), x);
     emitted++;
   }
   __device__ __forceinline__ void horner(u64 x) {      // constraints listed last to first: Horner with alpha
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) acc[c] = gl_add(gl_mul(acc[c], step[c]), x);
+      if (c < CH) acc[c] = gl_add_nc(gl_mul_nc(acc[c], step[c]), x);
   }
 };
 __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {

@@ -237,3 +237,81 @@ extern "C" int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, size_t 
   if (failed_check) *failed_check = rc;
   return rc == 0 ? LCP2_OK : LCP2_E_VERIFY;
 }
+
+// ------------------------------------------------------------------ proof <-> bytes (plonky2 util/serialization.rs, [RECALL])
+namespace {
+// walks the flat proof in field order; `word` sees every field element slot, `count` every MerkleProof sibling-count byte
+template <class Word, class Count>
+bool walk_proof(const lcp2_params &p, Word &&word, Count &&count) {
+  const ProofLayout L(p);
+  const size_t CH = p.num_challenges, NR = p.num_routed_wires, NC = p.num_constants, W = p.num_wires, Q = p.quotient_degree_factor;
+  const size_t npp = (NR + Q - 1) / Q - 1;
+  auto run = [&](size_t off, size_t n) { for (size_t i = 0; i < n; i++) if (!word(off + i)) return false; return true; };
+  if (!run(L.wires_cap, 3 * L.capw)) return false;
+  // OpeningSet: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys (the flat layout's order)
+  if (!run(L.op_constants, 2 * (NC + NR + W)) || !run(L.op_zs, 2 * CH) || !run(L.op_zs_next, 2 * CH) || !run(L.op_pp, 2 * CH * npp) || !run(L.op_quot, 2 * CH * Q)) return false;
+  if (!run(L.fri_caps, p.num_fri_layers * L.capw)) return false;
+  for (u32 q = 0; q < p.num_query_rounds; q++) {
+    const size_t R = L.queries + (size_t)q * L.query_words;
+    for (int o = 0; o < 4; o++) {
+      if (!run(R + L.q_init_off[o], L.q_init_cols[o])) return false;
+      if (!count(L.q_init_sib)) return false;
+      if (!run(R + L.q_init_off[o] + L.q_init_cols[o], 4 * L.q_init_sib)) return false;
+    }
+    for (u32 l = 0; l < p.num_fri_layers; l++) {
+      const size_t ev = (size_t)2 << p.fri_arity_bits[l];
+      if (!run(R + L.q_step_off[l], ev)) return false;
+      if (!count(L.q_step_sib[l])) return false;
+      if (!run(R + L.q_step_off[l] + ev, 4 * L.q_step_sib[l])) return false;
+    }
+  }
+  return run(L.final_poly, 2 * L.final_len) && run(L.pow_witness, 1);
+}
+bool params_ok(const lcp2_params *p) {
+  return p && p->degree_bits >= 1 && p->degree_bits + p->rate_bits <= 30 && p->cap_height <= p->degree_bits + p->rate_bits &&
+         p->num_fri_layers <= LCP2_MAX_FRI_LAYERS && p->num_query_rounds <= 64 && p->quotient_degree_factor >= 1 && p->num_routed_wires >= 1 &&
+         p->num_routed_wires <= p->num_wires && p->num_wires <= 65535 && p->num_constants <= 65535 && p->num_challenges >= 1 && p->num_challenges <= 4;
+}
+inline void put64(uint8_t *o, u64 v) { for (int i = 0; i < 8; i++) o[i] = (uint8_t)(v >> (8 * i)); }
+inline u64 get64(const uint8_t *o) { u64 v = 0; for (int i = 0; i < 8; i++) v |= (u64)o[i] << (8 * i); return v; }
+}  // namespace
+
+extern "C" size_t lcp2_proof_bytes(const lcp2_params *p, size_t npi, uint32_t flags) {
+  if (!params_ok(p)) return 0;
+  size_t n = 0;
+  walk_proof(*p, [&](size_t) { n += 8; return true; }, [&](size_t) { n += 1; return true; });
+  return n + 8 * npi + ((flags & LCP2_SER_PUBLIC_INPUT_COUNT) ? 8 : 0);
+}
+extern "C" int lcp2_proof_to_bytes(const lcp2_params *p, const uint64_t *proof, size_t proof_words, const uint64_t *pis, size_t npi, uint32_t flags,
+                                   uint8_t *out, size_t out_len) {
+  if (!params_ok(p) || !proof || !out || (npi && !pis)) return LCP2_E_INVALID;
+  if (proof_words != ProofLayout(*p).total || out_len != lcp2_proof_bytes(p, npi, flags)) return LCP2_E_INVALID;
+  size_t pos = 0;
+  bool ok = walk_proof(*p, [&](size_t w) { if (proof[w] >= GL_P) return false; put64(out + pos, proof[w]); pos += 8; return true; },
+                       [&](size_t nsib) { if (nsib > 255) return false; out[pos++] = (uint8_t)nsib; return true; });
+  if (!ok) return LCP2_E_INVALID;
+  if (flags & LCP2_SER_PUBLIC_INPUT_COUNT) { put64(out + pos, npi); pos += 8; }
+  for (size_t i = 0; i < npi; i++) { put64(out + pos, gl_canon(pis[i])); pos += 8; }
+  return pos == out_len ? LCP2_OK : LCP2_E_INVALID;
+}
+extern "C" int lcp2_proof_from_bytes(const lcp2_params *p, const uint8_t *bytes, size_t len, uint32_t flags, uint64_t *proof, size_t proof_words,
+                                     uint64_t *pis, size_t npi) {
+  if (!params_ok(p) || !bytes || !proof || (npi && !pis)) return LCP2_E_INVALID;
+  if (proof_words != ProofLayout(*p).total || len != lcp2_proof_bytes(p, npi, flags)) return LCP2_E_INVALID;  // nothing is read past `len`
+  size_t pos = 0;
+  bool ok = walk_proof(*p, [&](size_t w) { const u64 v = get64(bytes + pos); pos += 8; if (v >= GL_P) return false; proof[w] = v; return true; },
+                       [&](size_t nsib) { return bytes[pos++] == (uint8_t)nsib && nsib <= 255; });
+  if (!ok) return LCP2_E_INVALID;
+  if (flags & LCP2_SER_PUBLIC_INPUT_COUNT) { if (get64(bytes + pos) != npi) return LCP2_E_INVALID; pos += 8; }
+  for (size_t i = 0; i < npi; i++) { const u64 v = get64(bytes + pos); pos += 8; if (v >= GL_P) return LCP2_E_INVALID; pis[i] = v; }
+  return LCP2_OK;
+}
+extern "C" int lcp2_verifier_data_to_bytes(const lcp2_circuit *c, uint8_t *out, size_t out_len) {
+  if (!c || !out) return LCP2_E_INVALID;
+  const VerifierView v = verifier_view(c);
+  const size_t capw = (size_t)4 << v.p->cap_height;
+  if (out_len != (capw + 4) * 8) return LCP2_E_INVALID;
+  for (size_t i = 0; i < capw; i++) put64(out + 8 * i, v.cs_cap[i]);
+  for (size_t i = 0; i < 4; i++) put64(out + 8 * (capw + i), v.digest[i]);
+  return LCP2_OK;
+}

@@ -332,6 +332,26 @@ int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap);
 int lcp2_verify(const lcp2_circuit *c, const uint64_t *proof, size_t proof_words, const uint64_t *public_inputs,
                 size_t num_public_inputs, int *failed_check);
 
+/* ---- byte serialisation of a proof: plonky2 0.1.4 util/serialization.rs `write_proof_with_public_inputs`
+ * ([RECALL] of the published format; the reference holds no serialised proof - src/main.rs:230-233 moves the object - so
+ * this layout is PARITY UNPINNED).  Little-endian throughout: a field element is its canonical u64, an extension element two
+ * of them, a hash four; Merkle caps and opening vectors carry no length (the reader knows them from CommonCircuitData);
+ * every MerkleProof is a u8 sibling count followed by the siblings; field order: wires_cap, plonk_zs_partial_products_cap,
+ * quotient_polys_cap, openings { constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys },
+ * opening_proof { commit_phase_merkle_caps, query_round_proofs { initial_trees_proof { (leaf, proof) x 4 }, steps { evals,
+ * proof } }, final_poly, pow_witness }, then the public inputs, preceded by their count as a u64 when
+ * LCP2_SER_PUBLIC_INPUT_COUNT is set (later 0.1.x snapshots write it, earlier ones do not).
+ * lcp2_proof_bytes: the byte length; lcp2_proof_to_bytes / lcp2_proof_from_bytes: LCP2_E_INVALID on a length mismatch, a
+ * non-canonical element or a wrong sibling count (nothing is read past `len`). */
+#define LCP2_SER_PUBLIC_INPUT_COUNT 1u
+size_t lcp2_proof_bytes(const lcp2_params *p, size_t num_public_inputs, uint32_t flags);
+int lcp2_proof_to_bytes(const lcp2_params *p, const uint64_t *proof, size_t proof_words, const uint64_t *public_inputs,
+                        size_t num_public_inputs, uint32_t flags, uint8_t *out, size_t out_len);
+int lcp2_proof_from_bytes(const lcp2_params *p, const uint8_t *bytes, size_t len, uint32_t flags, uint64_t *proof, size_t proof_words,
+                          uint64_t *public_inputs, size_t num_public_inputs);
+/* VerifierOnlyCircuitData { constants_sigmas_cap, circuit_digest }: the cap's hashes, then the digest ((4 << cap_height) + 4) * 8 bytes */
+int lcp2_verifier_data_to_bytes(const lcp2_circuit *c, uint8_t *out, size_t out_len);
+
 /* Verifier-only circuit (VerifierCircuitData): no device, no context.  Takes the gate set, k_is and
  * parameters from `desc` (constants_sigmas is ignored and may be NULL) plus the circuit digest and the
  * constants_sigmas cap published by the prover's build().  lcp2_prove on it returns LCP2_E_NODEVICE. */

@@ -185,3 +185,53 @@ def test_plonky2_gate_programs_hold_on_their_witness_rows(oracle):
     w2[pos.W_DELTA, prow] ^= np.uint64(1)
     assert oc.check_witness(w2, pis)[0] > 0
     oc.close()
+
+
+def test_proof_byte_serialisation_round_trip(oracle):
+    """ProofWithPublicInputs <-> bytes (plonky2 util/serialization.rs layout, PARITY UNPINNED: the reference holds no serialised
+    proof).  Round trip, exact size, u8 sibling counts where the layout says, and every malformed buffer is refused."""
+    import struct
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(6, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=12)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    proof = oc.prove(wires, pis)
+    vd = m.CircuitData.verifier_only(circ, *oc.digest())
+    for flags in (0, m.binding.SER_PUBLIC_INPUT_COUNT):
+        data = m.proof_to_bytes(params, proof, pis, flags)
+        nsib_lists = params.num_query_rounds * (4 + params.num_fri_layers)
+        assert len(data) == 8 * proof.size + nsib_lists + 8 * len(pis) + (8 if flags else 0)
+        back, back_pis = m.proof_from_bytes(params, data, len(pis), flags)
+        assert (back == proof).all() and (back_pis == pis).all()
+        vd.verify(back, back_pis)
+    # layout spot checks: the three caps come first as plain little-endian words; the first MerkleProof of the first query round
+    # starts with its sibling count (lg(8n) - cap_height) as one byte, right after the constants/sigmas leaf
+    capw = 4 << params.cap_height
+    assert list(struct.unpack("<%dQ" % (3 * capw), data[:24 * capw])) == [int(x) for x in proof[:3 * capw]]
+    NC, NR, W, CH, Q = params.num_constants, params.num_routed_wires, params.num_wires, params.num_challenges, params.quotient_degree_factor
+    npp = -(-NR // Q) - 1
+    openings = 2 * (NC + NR + W + CH + CH + CH * npp + CH * Q)
+    first_query = 8 * (3 * capw + openings + params.num_fri_layers * capw)
+    assert data[first_query + 8 * (NC + NR)] == params.degree_bits + params.rate_bits - params.cap_height
+    # the public inputs are the tail, preceded by their count
+    assert struct.unpack("<Q", data[-8 * len(pis) - 8:-8 * len(pis)])[0] == len(pis)
+    # malformed buffers
+    for bad in (data[:-1], data + b"\\0", data[:100]):
+        with pytest.raises(m.Lcp2Error):
+            m.proof_from_bytes(params, bad, len(pis))
+    tampered = bytearray(data)
+    tampered[first_query + 8 * (NC + NR)] ^= 1          # a sibling count
+    with pytest.raises(m.Lcp2Error):
+        m.proof_from_bytes(params, bytes(tampered), len(pis))
+    tampered = bytearray(data)
+    tampered[0:8] = struct.pack("<Q", 2 ** 64 - 1)       # a non-canonical field element
+    with pytest.raises(m.Lcp2Error):
+        m.proof_from_bytes(params, bytes(tampered), len(pis))
+    with pytest.raises(m.Lcp2Error):
+        m.proof_from_bytes(params, data, len(pis) + 1)
+    # VerifierOnlyCircuitData: cap then digest
+    vb = vd.verifier_data_bytes()
+    digest, cap = oc.digest()
+    assert vb == cap.tobytes() + digest.tobytes()
+    oc.close()
+    vd.close()
