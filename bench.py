@@ -6,10 +6,14 @@
 A step = one `data.prove(witness)` (the region the reference times, eth-lc-plonky2/src/main.rs:229-232)
 over the BASELINE workload configs[2]: a light-client-sized circuit, n = 2^22 rows, 135 wires (80 routed),
 standard_recursion_config (rate 1/8, cap height 4, 2 challenges, quotient degree factor 8, 5 arity-16 FRI
-layers, 16 PoW bits, 28 queries).  The real gate set of plonky2 / plonky2_crypto is not visible from the
-reference, so the circuit is the synthetic satisfiable one of eth-lc-plonky2_amd/circuit.py (arithmetic,
-constant, public-input, degree-7 and no-op gates with real copy constraints); the witness is resident in
-HBM when the timed region starts and the proof produced in the last step is checked by the verifier.
+layers, 16 PoW bits, 28 queries).  The circuit is the synthetic satisfiable one of
+eth-lc-plonky2_amd/circuit.py over plonky2's own gate set (NoopGate, ConstantGate, PublicInputGate,
+BaseSumGate<2>, ArithmeticGate, PoseidonGate as gate programs; the public inputs hashed in-circuit as
+circuit_builder.rs::build does; real copy constraints); the witness is resident in HBM when the timed region
+starts and the proof produced in the last step is checked by the verifier.  Two side fields carry the same
+prover on circuits built from the reference's own gadgets by the C++ host layer, device-side witness
+generation included: `config.real_lc_step` (updates 633 -> 634, 2^19 rows in the own SHA-256 layout) and
+`config.real_gadget_circuit_2p22` (the step plus six more SyncCommitteeSSZ gadgets: 2.24 M gates, 2^22 rows).
 
 N > 1: one rank per GPU, every rank proves its own witness of the same circuit (BASELINE configs[4],
 independent light-client updates: "replicas", no data-path collective) -> weak scaling; the only
@@ -60,7 +64,7 @@ def valu_roofline(perms_per_s):
             "floor_exceeded_by": ratio if ratio > 1.0 else None,
             "cycles_per_valu_instruction_per_simd": 256 * 4 * 64 * CLOCK_HZ / lane_instr}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")  # k_hash_leaves is unchanged since that pass  # tools/pmc_traffic.py on the --pmc passes of this bench
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench (tools/collect_profiles.sh)
 
 
 def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
@@ -290,7 +294,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: full light-client-sized proof, n=2^%d rows x 135 wires, standard_recursion_config, "
-                                   "synthetic satisfiable gate-program circuit, recursive BLS verifier stubbed" % a.degree_bits,
+                                   "synthetic satisfiable circuit over plonky2's own gate set (Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon; public inputs hashed in-circuit), recursive BLS verifier stubbed" % a.degree_bits,
                        "degree_bits": a.degree_bits, "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
                        "parallelism": "replicas x%d (one independent proof per GPU)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

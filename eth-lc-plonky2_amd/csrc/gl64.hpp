@@ -207,6 +207,15 @@ LCP2_HD u64 gl_root_of_unity(unsigned k) {
   return r;
 }
 
+// x * 2^S mod p for 0 < S < 64: the product is the 128-bit value (x >> (64 - S)) : (x << S), so the multiply is two shifts and the
+// reduction (the compiler drops the hi_hi part for S <= 32).  The 16th roots of unity of the field are powers of two
+// (w_16 = 2^12, because 2^96 = -1), which is what the register butterflies of the NTT multiply by.
+template <unsigned S>
+LCP2_HD u64 gl_shl(u64 x) {
+  static_assert(S > 0 && S < 64, "shift out of range");
+  return gl_reduce128(x << S, x >> (64 - S));
+}
+
 struct gl2 {
   u64 c0, c1;
 };

@@ -47,11 +47,13 @@ constexpr u32 NTT_MAX_STRIDED_B = 9;
 constexpr u32 NTT_SEG_BITS = 4;     // 16 x 8 B = 128-byte runs in strided passes
 constexpr u32 NTT_BATCH = 4;        // elements (butterflies) in flight per thread
 
-struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h]
+struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h];  h = NTT_DIRECT: one level, value(e) = lo[e]
   const u64 *lo;
   const u64 *hi;
   u32 h;
 };
+constexpr u32 NTT_DIRECT = 63;
+constexpr u32 NTT_DIRECT_MAX_LG = 22;  // one-level tables up to 2^22 entries (32 MiB) per table row
 
 struct NttPassParams {
   const u64 *in;
@@ -77,8 +79,42 @@ struct NttPassParams {
 LCP2_HD u32 lds_phys(u32 i) { return i + (i >> 4); }
 LCP2_HD u32 ntt_lds_words(u32 L) { return (1u << L) + ((1u << L) >> 4) + 1; }
 
-// 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out; dit: bit-reversed in -> natural out
-// (wr holds the inverse roots there).  wr[k] = w_16^k.
+// The 16th roots of unity of the field are powers of two: 2 has order 192 (2^96 = -1) and plonky2's w_16 (the generator's
+// power) is 2^156 = -2^60, so w_16^k = +-2^s for every k.  Where s < 64 the twiddle multiply of a register butterfly is a
+// shift-reduce (gl_shl, ~13 instructions against 21 for a general multiply) and the sign goes into the order of the
+// subtraction; 2^72 and 2^84 (k = 3, 6 forward; k = 2, 5 inverse) overflow the 128-bit shift and stay general multiplies by
+// the constant wr[k].  tests/emu and the GPU parity tests compare the transforms with the oracle's textbook radix-2 NTT.
+//   forward  w^k : k=1 -2^60  k=2 -2^24  k=3 2^84   k=4  2^48  k=5  2^12  k=6 -2^72  k=7 -2^36
+//   inverse w^-k : k=1  2^36  k=2  2^72  k=3 -2^12  k=4 -2^48  k=5 -2^84  k=6  2^24  k=7  2^60
+// (a - b) * w_16^k
+LCP2_HD u64 ntt_dif_twiddle(u64 a, u64 b, u32 k, const u64 *wr) {
+  switch (k) {
+    case 1: return gl_shl<60>(gl_sub(b, a));
+    case 2: return gl_shl<24>(gl_sub(b, a));
+    case 4: return gl_shl<48>(gl_sub(a, b));
+    case 5: return gl_shl<12>(gl_sub(a, b));
+    case 7: return gl_shl<36>(gl_sub(b, a));
+    default: return gl_mul(gl_sub(a, b), wr[k]);
+  }
+}
+// (a + x w_16^-k, a - x w_16^-k)
+LCP2_HD void ntt_dit_butterfly(u64 a, u64 x, u32 k, const u64 *wr_inv, u64 &sum, u64 &diff) {
+  u64 b;
+  bool neg = false;
+  switch (k) {
+    case 1: b = gl_shl<36>(x); break;
+    case 3: b = gl_shl<12>(x); neg = true; break;
+    case 4: b = gl_shl<48>(x); neg = true; break;
+    case 6: b = gl_shl<24>(x); break;
+    case 7: b = gl_shl<60>(x); break;
+    default: b = gl_mul(x, wr_inv[k]); break;
+  }
+  sum = neg ? gl_sub(a, b) : gl_add(a, b);
+  diff = neg ? gl_add(a, b) : gl_sub(a, b);
+}
+
+// 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out (wr[k] = w_16^k); dit: bit-reversed in ->
+// natural out (wr[k] = w_16^-k).
 template <u32 RB>
 LCP2_HD void ntt_reg_dif(u64 *x, const u64 *wr) {
   constexpr u32 R = 1u << RB;
@@ -90,8 +126,7 @@ LCP2_HD void ntt_reg_dif(u64 *x, const u64 *wr) {
       const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
       const u64 a = x[i0], b = x[i1];
       x[i0] = gl_add(a, b);
-      const u64 d = gl_sub(a, b);
-      x[i1] = i ? gl_mul(d, wr[i * (8 / half)]) : d;
+      x[i1] = i ? ntt_dif_twiddle(a, b, i * (8 / half), wr) : gl_sub(a, b);
     }
   }
 }
@@ -104,14 +139,20 @@ LCP2_HD void ntt_reg_dit(u64 *x, const u64 *wr) {
 #pragma unroll
     for (u32 q = 0; q < R / 2; q++) {
       const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
-      const u64 a = x[i0], b = i ? gl_mul(x[i1], wr[i * (8 / half)]) : x[i1];
-      x[i0] = gl_add(a, b);
-      x[i1] = gl_sub(a, b);
+      const u64 a = x[i0];
+      if (i) {
+        ntt_dit_butterfly(a, x[i1], i * (8 / half), wr, x[i0], x[i1]);
+      } else {
+        const u64 b = x[i1];
+        x[i0] = gl_add(a, b);
+        x[i1] = gl_sub(a, b);
+      }
     }
   }
 }
 
 LCP2_HD u64 two_level(const TwoLevelTable &t, u64 e) {
+  if (t.h == NTT_DIRECT) return t.lo[e];
   return gl_mul(t.lo[e & ((1ull << t.h) - 1)], t.hi[e >> t.h]);
 }
 
@@ -143,6 +184,7 @@ struct NttPass {
   LCP2_HD u64 group_twiddle(u32 wg, u32 local) const {
     u64 l = low_bits(wg, local);
     u32 tp = (local >> p.S) & ((1u << p.B) - 1);
+    if (p.tw.h == NTT_DIRECT) return p.tw.lo[((u64)tp << p.g_lo) | l];  // [t'][l] = w^(l * bitrev(t')): consecutive lanes, consecutive words
     u64 k1 = bitrev32(tp, p.B);
     return two_level(p.tw, l * k1);
   }
@@ -154,23 +196,24 @@ struct NttPass {
     const u64 *src = p.in + (u64)col * p.in_col_stride + (u64)z * p.in_z_stride;
     const u32 n = 1u << p.L;
     for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
-      u64 g[NTT_BATCH], v[NTT_BATCH];
+      u64 g[NTT_BATCH], v[NTT_BATCH], f[NTT_BATCH];
+      // one-level factor tables are plain loads: issue them with the data (a two-level factor costs a multiply and waits)
+      const bool factor = INV ? p.g_lo != 0 : p.scale_mode != 0;
+      const bool early = factor && (INV ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT));
 #pragma unroll
       for (u32 j = 0; j < NTT_BATCH; j++) {
         u32 i = i0 + j * nthr;
-        g[j] = global_index(wg, i < n ? i : 0);  // out-of-range lanes re-read element 0 (always valid)
+        if (i >= n) i = 0;  // out-of-range lanes re-read element 0 (always valid)
+        g[j] = global_index(wg, i);
         v[j] = src[g[j]];
+        if (early) f[j] = INV ? group_twiddle(wg, i) : scale_at(g[j], z);
       }
 #pragma unroll
       for (u32 j = 0; j < NTT_BATCH; j++) {
         u32 i = i0 + j * nthr;
         if (i >= n) continue;
         u64 x = gl_canon(v[j]);
-        if (!INV) {
-          if (p.scale_mode) x = gl_mul(x, scale_at(g[j], z));
-        } else {
-          if (p.g_lo) x = gl_mul(x, group_twiddle(wg, i));
-        }
+        if (factor) x = gl_mul(x, early ? f[j] : (INV ? group_twiddle(wg, i) : scale_at(g[j], z)));
         lds[lds_phys(i)] = x;
       }
     }

@@ -45,6 +45,28 @@ struct NttHost {
     for (int k = 0; k < 8; k++) { p.wr[k] = cur; cur = gl_mul(cur, w16); }
     p.nsteps = ntt_step_plan(p.B, p.S, p.step_plan);
   }
+  // inter-group twiddles w_{2^(g_lo + B)}^(l * bitrev(t')) of a strided pass as ONE table indexed [t'][l]: a single coalesced
+  // load per element instead of two lookups and a multiply (the table is shared by every column and coset: cache resident)
+  TwoLevelTable group_twiddle_table(u32 g_lo, u32 B, bool inv) {
+    const u32 lg = g_lo + B;
+    if (lg > NTT_DIRECT_MAX_LG) return root_table(lg, inv);
+    TwoLevelTable t;
+    t.h = NTT_DIRECT;
+    t.hi = nullptr;
+    t.lo = be.table(key("grouptw", g_lo, B, inv), [=] {
+      u64 w = gl_root_of_unity(lg);
+      if (inv) w = gl_inv(w);
+      std::vector<u64> out((size_t)1 << lg);
+      for (u32 tp = 0; tp < (1u << B); tp++) {
+        const u64 step = gl_pow(w, bitrev32(tp, B));
+        u64 cur = 1;
+        u64 *row = out.data() + ((size_t)tp << g_lo);
+        for (u64 l = 0; l < (1ull << g_lo); l++) { row[l] = cur; cur = gl_mul(cur, step); }
+      }
+      return out;
+    });
+    return t;
+  }
   TwoLevelTable root_table(u32 lg, bool inv) {
     TwoLevelTable t;
     t.h = (lg + 1) / 2;
@@ -63,8 +85,28 @@ struct NttHost {
   }
   // shift_z^j tables for z = 0..nz-1, shift_z = base * w_{2^(lg+zbits)}^z  (z = 0 only when zbits = 0);
   // inverse: (shift^-1)^j scaled by `scalar`.
-  TwoLevelTable shift_table(u64 base, u32 lg, u32 zbits, bool inv, u64 scalar, u64 &lo_stride, u64 &hi_stride) {
+  TwoLevelTable shift_table(u64 base, u32 lg, u32 zbits, bool inv, u64 scalar, u64 &lo_stride, u64 &hi_stride, bool allow_direct = false) {
     TwoLevelTable t;
+    if (allow_direct && lg <= NTT_DIRECT_MAX_LG && lg >= 14) {  // one row of 2^lg powers per coset: one coalesced load, no multiply
+      const u32 nzd = 1u << zbits;
+      t.h = NTT_DIRECT;
+      t.hi = nullptr;
+      lo_stride = (u64)1 << lg;
+      hi_stride = 0;
+      t.lo = be.table(key("shdirect", base, lg * 64 + zbits * 2 + inv, scalar), [=] {
+        std::vector<u64> all;
+        all.reserve((size_t)nzd << lg);
+        for (u32 z = 0; z < nzd; z++) {
+          u64 sft = base;
+          if (zbits) sft = gl_mul(sft, gl_pow(gl_root_of_unity(lg + zbits), z));
+          if (inv) sft = gl_inv(sft);
+          auto v = make_pow_table(sft, 1, (size_t)1 << lg, scalar);
+          all.insert(all.end(), v.begin(), v.end());
+        }
+        return all;
+      });
+      return t;
+    }
     t.h = (lg + 1) / 2;
     u32 h = t.h;
     u32 nz = 1u << zbits;
@@ -116,14 +158,14 @@ struct NttHost {
       bool first = gi == 0;
       p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
       set_group(p, false);
-      if (g.g_lo) p.tw = root_table(g.g_lo + g.B, false);
+      if (g.g_lo) p.tw = group_twiddle_table(g.g_lo, g.B, false);
       u32 wgs, nz;
       if (first) {
         p.in = in; p.in_col_stride = in_col_stride; p.in_z_stride = 0;
         p.out = out; p.out_col_stride = out_col_stride; p.out_z_stride = (u64)1 << lg; p.zbits = zbits;
         if (shift != 1 || zbits) {
           p.scale_mode = 2;
-          p.sc = shift_table(shift, lg, zbits, false, 1, p.sc_lo_z_stride, p.sc_hi_z_stride);
+          p.sc = shift_table(shift, lg, zbits, false, 1, p.sc_lo_z_stride, p.sc_hi_z_stride, true);
         }
         wgs = 1u << (lg - g.L);
         nz = 1u << zbits;
@@ -158,7 +200,7 @@ struct NttHost {
       NttPassParams p{};
       p.L = g.L; p.S = g.S; p.B = g.B; p.g_lo = g.g_lo;
       set_group(p, true);
-      if (g.g_lo) p.tw = root_table(g.g_lo + g.B, true);
+      if (g.g_lo) p.tw = group_twiddle_table(g.g_lo, g.B, true);
       bool firstpass = gi == ng - 1, lastpass = gi == 0;
       p.in = firstpass ? in : out; p.in_col_stride = firstpass ? in_col_stride : out_col_stride;
       p.out = out; p.out_col_stride = out_col_stride;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): every measurement DESIGN.md / bench.py quote for one round, into $1 (under gpurun_out/).
+#   rocprofv3 kernel trace + stats of bench.py, FETCH_SIZE and WRITE_SIZE PMC passes (separate, as MI355X_MICROARCH.md prescribes),
+#   SQ counters of a 2^20 proof, kernel traces of the real light-client step, the plain bench line, the instruction-rate ubench.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=$1
+mkdir -p $out
+B="python3 bench.py --no-cpu-baseline --no-real-gadgets"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B --steps 2 --warmup 1 > $out/bench_under_rocprof.json 2> $out/kt.err && \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B --steps 1 --warmup 0 > $out/bench_under_pmc_fetch.json 2> $out/fetch.err && \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- $B --steps 1 --warmup 0 > $out/bench_under_pmc_write.json 2> $out/write.err && \
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o sq -- python3 tools/prof_prove.py 22 1 > $out/sq.log 2>&1 && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/lc -o lc -- ./examples/lc_prover tmp_fixtures/u633.json tmp_fixtures/u634.json --repeat 2 > $out/lc.log 2>&1 && \
+./tools/ubench/int_rates > $out/ubench.txt 2>&1 && \
+python3 bench.py > $out/bench.json 2> $out/bench.err
+echo "collect rc=$?"
+find $out -name "*.csv" | head -30

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Copies one round's measurement set from gpurun_out/ into profiles/ under a common tag and derives the summaries:
-    python tools/install_profiles.py r01_v8 8
-expects gpurun_out/{r01_vN_bench.log, r01_vN_bench_under_rocprof.log, prof_vN/vN_kernel_stats.csv, pmc_fetchN/, pmc_writeN/, pmc_valuN/}."""
+"""Copies one round's measurement set (tools/collect_profiles.sh on the GPU box -> gpurun_out/<dir>) into profiles/ under a common
+tag and derives the summaries:
+    python tools/install_profiles.py gpurun_out/r02_final r02
+-> profiles/<tag>_bench.json, _bench_under_rocprof.json, _full_proof_kernel_stats.csv, _pmc_fetch/_write counter csv,
+   _pmc_traffic.json (tools/pmc_traffic.py), _sq_counters.csv (per kernel, per launch), _lc_step_kernel_stats.csv, _ubench_int_rates.txt"""
 import collections
 import csv
 import os
@@ -9,40 +11,60 @@ import shutil
 import subprocess
 import sys
 
-tag, n = sys.argv[1], sys.argv[2]
+src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-g, p = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+p = os.path.join(root, "profiles")
 
 
-def json_line(src, dst):
-    lines = [l for l in open(src) if l.startswith('{"metric"')]
-    open(dst, "w").write(lines[-1])
+def json_line(a, b):
+    lines = [l for l in open(a) if l.startswith('{"metric"')]
+    open(b, "w").write(lines[-1])
 
 
-json_line(f"{g}/{tag}_bench.log", f"{p}/{tag}_bench.json")
-json_line(f"{g}/{tag}_bench_under_rocprof.log", f"{p}/{tag}_bench_under_rocprof.json")
-json_line(f"{g}/pmc_fetch{n}.log", f"{p}/{tag}_bench_under_pmc_fetch.json")
-shutil.copy(f"{g}/prof_v{n}/v{n}_kernel_stats.csv", f"{p}/{tag}_full_proof_kernel_stats.csv")
-shutil.copy(f"{g}/pmc_fetch{n}/fetch_counter_collection.csv", f"{p}/{tag}_pmc_fetch_size_counter_collection.csv")
-shutil.copy(f"{g}/pmc_write{n}/write_counter_collection.csv", f"{p}/{tag}_pmc_write_size_counter_collection.csv")
+json_line(f"{src}/bench.json", f"{p}/{tag}_bench.json")
+json_line(f"{src}/bench_under_rocprof.json", f"{p}/{tag}_bench_under_rocprof.json")
+json_line(f"{src}/bench_under_pmc_fetch.json", f"{p}/{tag}_bench_under_pmc_fetch.json")
+shutil.copy(f"{src}/kt/kt_kernel_stats.csv", f"{p}/{tag}_full_proof_kernel_stats.csv")
+shutil.copy(f"{src}/lc/lc_kernel_stats.csv", f"{p}/{tag}_lc_step_kernel_stats.csv")
+shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
+for which in ("fetch", "write"):
+    # keep the per-dispatch counter rows of the library's kernels only (the full csv is tens of MB)
+    rows = list(csv.DictReader(open(f"{src}/{which}/{which}_counter_collection.csv")))
+    keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value",
+            "Start_Timestamp", "End_Timestamp"]
+    with open(f"{p}/{tag}_pmc_{which}_size_counter_collection.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=keep)
+        w.writeheader()
+        for r in rows:
+            if "lcp2::" in r["Kernel_Name"]:
+                r = {k: r[k] for k in keep}
+                r["Kernel_Name"] = r["Kernel_Name"].split("(")[0]
+                w.writerow(r)
 subprocess.run([sys.executable, f"{root}/tools/pmc_traffic.py", f"{p}/{tag}_pmc_fetch_size_counter_collection.csv",
-                f"{p}/{tag}_pmc_write_size_counter_collection.csv", f"{g}/pmc_fetch{n}.log", f"{p}/{tag}_pmc_traffic.json"], check=True,
-               stdout=subprocess.DEVNULL)
+                f"{p}/{tag}_pmc_write_size_counter_collection.csv", f"{p}/{tag}_bench_under_pmc_fetch.json", f"{p}/{tag}_pmc_traffic.json"], check=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(f"{g}/pmc_valu{n}/v_counter_collection.csv")):
+seen = set()
+for r in csv.DictReader(open(f"{src}/sq/sq_counter_collection.csv")):
     k = r["Kernel_Name"]
-    if "lcp2::" in k:
-        key = k.split("(")[0].replace("void ", "").replace("lcp2::", "")
-        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "lcp2::" not in k:
+        continue
+    key = k.split("(")[0].replace("void ", "").replace("lcp2::", "")
+    acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if (r["Dispatch_Id"], key) not in seen:
+        seen.add((r["Dispatch_Id"], key))
         acc[key]["dur_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-with open(f"{p}/{tag}_valu_counters.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- python3 tools/prof_commit.py 32 22 2\n")
-    f.write("# averages per launch (commitment of 32 columns at n = 2^22); GRBM_GUI_ACTIVE is summed over the 8 XCDs; clock = GRBM_GUI_ACTIVE / 8 / duration;\n")
-    f.write("# cycles_per_valu_instr_per_simd = (GRBM_GUI_ACTIVE / 8) / (SQ_INSTS_VALU / 1024 SIMDs)\n")
-    f.write("kernel,launches,avg_duration_ms,SQ_INSTS_VALU,GRBM_GUI_ACTIVE,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,clock_GHz,cycles_per_valu_instr_per_simd\n")
+        acc[key]["waves"].append(float(r["Grid_Size"]) / 64)
+        acc[key]["vgpr"].append(float(r["VGPR_Count"]))
+with open(f"{p}/{tag}_sq_counters.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python3 tools/prof_prove.py 22 1\n")
+    f.write("# one proof at n = 2^22 (plus build()); totals over the launches of each kernel; per_wave = total / waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs:\n")
+    f.write("# clock = GRBM_GUI_ACTIVE / 8 / duration; cycles_per_valu_instr_per_simd = (GRBM_GUI_ACTIVE / 8) / (SQ_INSTS_VALU / 1024 SIMDs)\n")
+    f.write("kernel,launches,total_ms,waves,vgpr,valu_per_wave,salu_per_wave,lds_per_wave,wait_any_frac_of_wave_cycles,clock_GHz,cycles_per_valu_instr_per_simd\n")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]["dur_ms"])):
-        avg = lambda c: sum(v[c]) / len(v[c]) if v[c] else 0.0  # noqa: E731
-        d, gui, iv = avg("dur_ms"), avg("GRBM_GUI_ACTIVE"), avg("SQ_INSTS_VALU")
-        f.write("%s,%d,%.4f,%.0f,%.0f,%.0f,%.0f,%.3f,%.2f\n" % (k, len(v["SQ_INSTS_VALU"]), d, iv, gui, avg("SQ_WAVE_CYCLES"), avg("SQ_BUSY_CYCLES"),
-                                                          gui / 8 / (d * 1e-3) / 1e9 if d else 0, (gui / 8) / (iv / 1024) if iv else 0))
-print(open(f"{p}/{tag}_valu_counters.csv").read().split("\n")[4:7])
+        tot = lambda c: sum(v[c])  # noqa: E731
+        waves, d = max(tot("waves"), 1), tot("dur_ms")
+        gui, iv = tot("GRBM_GUI_ACTIVE"), tot("SQ_INSTS_VALU")
+        f.write("%s,%d,%.3f,%d,%d,%.0f,%.0f,%.0f,%.3f,%.3f,%.2f\n" % (
+            k, len(v["dur_ms"]), d, waves, max(v["vgpr"]), iv / waves, tot("SQ_INSTS_SALU") / waves, tot("SQ_INSTS_LDS") / waves,
+            tot("SQ_WAIT_ANY") / max(tot("SQ_WAVE_CYCLES"), 1), gui / 8 / (d * 1e-3) / 1e9 if d else 0, (gui / 8) / (iv / 1024) if iv else 0))
+print(open(f"{p}/{tag}_sq_counters.csv").read())

@@ -42,5 +42,6 @@ hl["algorithmic_GB_per_launch_same_population"] = alg
 hl["traffic_over_algorithmic"] = (hl["read_GB_per_launch_corrected"] + hl["write_GB_per_launch"]) / alg
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out["kernels"]["k_hash_leaves"], indent=1))
-for k in ("k_quotient", "k_ntt_pass<false>", "k_ntt_pass<true>"):
-    print(k, out["kernels"].get(k))
+for k in sorted(out["kernels"]):
+    if k.startswith("k_q_") or k.startswith("k_ntt"):
+        print(k, out["kernels"][k])
