@@ -16,6 +16,7 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 u32p = ctypes.POINTER(ctypes.c_uint32)
 u8p = ctypes.POINTER(ctypes.c_uint8)
 MEM_HOST, MEM_DEVICE = 0, 1
+SECTION_OPENINGS, SECTION_FRI_CAP0, SECTION_AFTER_CAPS = 0, 1, 2
 
 K_INTT, K_LDE, K_LEAF_HASH, K_MERKLE, K_PERM_Z, K_QUOTIENT, K_OPENINGS, K_FRI, K_POW, K_SHA256, K_OTHER = range(11)
 KERNEL_FAMILIES = ["intt", "lde", "leaf_hash", "merkle", "perm_z", "quotient", "openings", "fri", "pow", "sha256", "other"]
@@ -122,6 +123,10 @@ def load_library():
         "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_fri_open": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
+        "lcp2_fri_open_begin": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
+        "lcp2_fri_open_commit": (c.c_int, [c.c_void_p, c.c_void_p]),
+        "lcp2_fri_open_finish": (c.c_int, [c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
+        "lcp2_proof_section": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_size_t), c.POINTER(c.c_size_t)]),
         "lcp2_challenger_init": (None, [c.POINTER(ChallengerState)]),
         "lcp2_challenger_observe": (c.c_int, [c.POINTER(ChallengerState), c.c_void_p, c.c_size_t]),
         "lcp2_challenger_get": (c.c_int, [c.POINTER(ChallengerState), c.c_void_p, c.c_size_t]),
@@ -554,6 +559,26 @@ class CircuitData:
         z = _np_u64(zeta)
         assert proof.dtype == np.uint64 and proof.size == self.proof_words and proof.flags.c_contiguous
         self._check(self.lib.lcp2_fri_open(self.handle, _ptr(z), ctypes.byref(challenger_state), _ptr(proof)))
+
+    # lcp2_fri_open in its three phases (the exchange points of a coset-sharded proof)
+    def fri_open_begin(self, zeta, challenger_state, proof):
+        z = _np_u64(zeta)
+        assert proof.dtype == np.uint64 and proof.size == self.proof_words and proof.flags.c_contiguous
+        self._check(self.lib.lcp2_fri_open_begin(self.handle, _ptr(z), ctypes.byref(challenger_state), _ptr(proof)))
+
+    def fri_open_commit(self, proof):
+        assert proof.dtype == np.uint64 and proof.size == self.proof_words and proof.flags.c_contiguous
+        self._check(self.lib.lcp2_fri_open_commit(self.handle, _ptr(proof)))
+
+    def fri_open_finish(self, proof, challenger_state=None):
+        assert proof.dtype == np.uint64 and proof.size == self.proof_words and proof.flags.c_contiguous
+        self._check(self.lib.lcp2_fri_open_finish(self.handle, ctypes.byref(challenger_state) if challenger_state is not None else None, _ptr(proof)))
+
+    def proof_section(self, section):
+        """(first word, word count) of SECTION_OPENINGS / SECTION_FRI_CAP0 / SECTION_AFTER_CAPS inside the proof array"""
+        first, count = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self.lib.lcp2_proof_section(self.handle, section, ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
 
     def verify(self, proof, public_inputs):
         """data.verify(proof): raises ProofRejected like the reference's unwrap()"""

@@ -12,6 +12,17 @@
 
 using namespace lcp2;
 
+// a batched opening in flight: lcp2_fri_open runs its three phases back to back, a coset-sharded proof exchanges the
+// openings after the first and the cap of FRI layer 0 after the second
+struct FriOpenState {
+  gl2 zeta{}, alpha{};
+  HostChallenger ch;
+  gl2 fri_betas[LCP2_MAX_FRI_LAYERS] = {};
+  u64 pow_witness = 0;
+  std::vector<u64> idx;
+  int phase = 0;  // 0: none, 1: openings evaluated, 2: final polynomial composed and FRI layer 0 committed
+};
+
 struct lcp2_circuit {
   lcp2_ctx *ctx = nullptr;
   lcp2_params p{};
@@ -38,6 +49,7 @@ struct lcp2_circuit {
   const u64 *d_wires_cur = nullptr;
   enum Stage { ST_NONE = 0, ST_WIRES, ST_ZS, ST_QVALS, ST_QUOT };  // what the handle holds of the proof in flight
   Stage stage = ST_NONE;
+  FriOpenState fo;
   // coset-sharded circuit: this handle holds the leaf blocks [bf, bf + bc) of every LDE and Merkle tree;
   // bc = 0: all of them.  cap_final: the full constants_sigmas cap (hence the digest) is known.
   uint32_t bf = 0, bc = 0;
@@ -332,6 +344,10 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
       u32 h = 0;
       while ((1ull << h) < nleaves) h++;
       u32 nlev = h - p.cap_height + 1;
+      if (l == 0 && c->sharded()) {  // its own leaf blocks only, down to its own cap entries: the same number of levels
+        nvals = (u64)c->bc * m;
+        nleaves = nvals >> p.fri_arity_bits[0];
+      }
       LCP2_HIP(ctx, c->fri_vals[l].alloc((size_t)2 * nvals * 8));
       c->fri_level_off[l].resize(nlev);
       u64 tot = 0;
@@ -341,7 +357,7 @@ static int circuit_create(lcp2_ctx *ctx, const lcp2_circuit_desc *d, uint32_t bf
       m >>= p.fri_arity_bits[l];
     }
   }
-  LCP2_HIP(ctx, c->q_idx.alloc(64 * 8 * (2 + LCP2_MAX_FRI_LAYERS)));
+  LCP2_HIP(ctx, c->q_idx.alloc(64 * 8 * (3 + LCP2_MAX_FRI_LAYERS)));
   LCP2_HIP(ctx, c->q_buf.alloc((size_t)64 * (ncs + p.num_wires + CH * (1 + npp) + CH * p.quotient_degree_factor + 4 * 4 * 32 + LCP2_MAX_FRI_LAYERS * (64 + 4 * 32)) * 8));
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LCP2_TRY(check_native_gates(c.get()));
@@ -609,33 +625,100 @@ int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash, u64 *
   return stage_quotient_commit(c, cap_out);
 }
 
-// OpeningSet::new + PolynomialBatch::prove_openings (K7-K9, a13).  `ch` has observed everything up to the quotient cap and
-// zeta was drawn from it; on return it has absorbed the openings, the FRI caps, the final polynomial and the PoW witness and
-// produced the query indices.  Writes proof words [op_constants, total).
-int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl2 &alpha, gl2 *fri_betas, u64 &pow_witness, std::vector<u64> &idx) {
+// OpeningSet::new + PolynomialBatch::prove_openings (K7-K9, a13) in three phases (state in c->fo).  The challenger has observed
+// everything up to the quotient cap and zeta was drawn from it; at the end it has absorbed the openings, the FRI caps, the final
+// polynomial and the PoW witness and produced the query indices.  Together the phases write proof words [op_constants, total).
+//
+// A coset-sharded circuit (rank = bf / bc of world = 2^rate_bits / bc) does a share of the first two phases:
+//   openings: the columns column_shard(rank) of every oracle (each rank holds all coefficients); zeros for the others
+//   commit:   FRI layer 0 (the big one: LDE, leaf hashing, Merkle levels) for its own leaf blocks; its cap entries at their
+//             global position.  Folding happens in coefficient form, so no values cross the ranks.
+// and the caller sums the shares (lcp2_proof_section) before the next phase.
+
+// first column and count of this rank's share of `nc` columns (the whole range for an unsharded circuit)
+void column_share(const lcp2_circuit *c, u32 nc, u32 &first, u32 &count) {
+  first = 0; count = nc;
+  if (!c->sharded()) return;
+  const u32 world = (1u << c->p.rate_bits) / c->bc, rank = c->bf / c->bc;
+  const u32 base = nc / world, extra = nc % world;
+  first = rank * base + std::min(rank, extra);
+  count = base + (rank < extra ? 1 : 0);
+}
+
+int fri_open_openings(lcp2_circuit *c, u64 *proof) {
   LCP2_STAGE_PROLOGUE
   if (c->stage != lcp2_circuit::ST_QUOT) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open: the quotient is not committed");
   if (!c->cap_final) return ctx->fail(LCP2_E_INVALID, "sharded circuit: lcp2_circuit_set_constants_cap has not been called");
-  const gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
-  // ---- K7a: openings
+  FriOpenState &fo = c->fo;
+  const gl2 zeta = fo.zeta, g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
   lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
-  {
-    u64 *d_tab = c->tables.u();
-    u64 *d_open = c->partial.u() + c->partial.bytes / 8 - 2 * (size_t)std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q));
-    std::vector<u64> tmp(2 * std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q)));
-    ProfScope ps(ctx, LCP2_K_OPENINGS, 8.0 * n * (ncs + W + CH * (1.0 + npp) + CH * Q + CH));
-    for (int o = 0; o < 4; o++) {
-      u32 nc = oracles[o]->ncols;
-      LCP2_TRY(eval_columns(c, oracles[o]->coeffs.u(), nc, zeta, d_open, d_tab));
-      LCP2_TRY(download(ctx, tmp.data(), d_open, 2 * nc * 8));
-      if (o == 0) memcpy(proof + L.op_constants, tmp.data(), 2 * nc * 8);  // constants then sigmas, contiguous
-      else if (o == 1) memcpy(proof + L.op_wires, tmp.data(), 2 * nc * 8);
-      else if (o == 2) { memcpy(proof + L.op_zs, tmp.data(), 2 * CH * 8); memcpy(proof + L.op_pp, tmp.data() + 2 * CH, 2 * CH * npp * 8); }
-      else memcpy(proof + L.op_quot, tmp.data(), 2 * nc * 8);
+  memset(proof + L.op_constants, 0, (L.total - L.op_constants) * 8);
+  u64 *d_tab = c->tables.u();
+  u64 *d_open = c->partial.u() + c->partial.bytes / 8 - 2 * (size_t)std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q));
+  std::vector<u64> tmp(2 * std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q)));
+  u32 share_cols = 0;
+  for (int o = 0; o < 4; o++) { u32 f, k; column_share(c, oracles[o]->ncols, f, k); share_cols += k; }
+  ProfScope ps(ctx, LCP2_K_OPENINGS, 8.0 * n * (share_cols + CH));
+  for (int o = 0; o < 4; o++) {
+    u32 first, nc;
+    column_share(c, oracles[o]->ncols, first, nc);
+    if (!nc) continue;
+    LCP2_TRY(eval_columns(c, oracles[o]->coeffs.u() + (size_t)first * n, nc, zeta, d_open, d_tab));
+    LCP2_TRY(download(ctx, tmp.data(), d_open, 2 * nc * 8));
+    for (u32 j = 0; j < nc; j++) {
+      const u32 col = first + j;
+      size_t at = o == 0 ? L.op_constants + 2 * col   // constants then sigmas, contiguous
+                : o == 1 ? L.op_wires + 2 * col
+                : o == 2 ? (col < CH ? L.op_zs + 2 * col : L.op_pp + 2 * (col - CH))
+                         : L.op_quot + 2 * col;
+      proof[at] = tmp[2 * j]; proof[at + 1] = tmp[2 * j + 1];
     }
+  }
+  if (!c->sharded() || c->bf == 0) {
     LCP2_TRY(eval_columns(c, c->zs.coeffs.u(), CH, g_zeta, d_open, d_tab));
     LCP2_TRY(download(ctx, proof + L.op_zs_next, d_open, 2 * CH * 8));
   }
+  fo.phase = 1;
+  return LCP2_OK;
+}
+
+// LDE of the coefficients in fri_c[cur] (m of them, zero padding to 8m implicit), leaf hashing and Merkle levels of FRI layer l;
+// the cap lands in the proof.  Layer 0 of a sharded circuit covers its own leaf blocks.
+int fri_commit_layer(lcp2_circuit *c, u32 l, int cur, u64 m, u64 shift, u64 *proof) {
+  LCP2_STAGE_PROLOGUE
+  const u32 ab = p.fri_arity_bits[l], arity = 1u << ab;
+  const bool part = l == 0 && c->sharded();
+  u32 lgm = 0;
+  while ((1ull << lgm) < m) lgm++;
+  const u64 nvals = part ? (u64)c->bc * m : m << p.rate_bits, nleaves = nvals >> ab;
+  u64 *vals = c->fri_vals[l].u();
+  {
+    ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * nvals + 32.0 * nleaves);
+    // coset_fft of the zero-padded coefficients = 2^rate_bits coset transforms of the m coefficients; leaf order out
+    if (part) ntt.forward(c->fri_c[cur].u(), m, vals, nvals, lgm, 2, shift, p.rate_bits, c->bf, c->bc);
+    else ntt.forward(c->fri_c[cur].u(), m, vals, nvals, lgm, 2, shift, p.rate_bits);
+    if (be.status) return be.status;
+    launch_hash_ext_leaves(s, vals, vals + nvals, arity, nleaves, c->fri_dig[l].u(), ctx->d_rc);
+    const auto &off = c->fri_level_off[l];
+    for (size_t k = 1; k < off.size(); k++)
+      launch_merkle_level(s, c->fri_dig[l].u() + 4 * off[k - 1], c->fri_dig[l].u() + 4 * off[k], nleaves >> k, ctx->d_rc);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+  u64 *cap = proof + L.fri_caps + l * L.capw;
+  const u64 *d_cap = c->fri_dig[l].u() + 4 * c->fri_level_off[l].back();
+  if (!part) return download(ctx, cap, d_cap, L.capw * 8);
+  const size_t per_block = (size_t)4 << (p.cap_height - p.rate_bits);
+  memset(cap, 0, L.capw * 8);
+  return download(ctx, cap + c->bf * per_block, d_cap, per_block * c->bc * 8);
+}
+
+int fri_open_commit(lcp2_circuit *c, u64 *proof) {
+  LCP2_STAGE_PROLOGUE
+  FriOpenState &fo = c->fo;
+  if (fo.phase != 1) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open_commit: call lcp2_fri_open_begin first");
+  HostChallenger &ch = fo.ch;
+  const gl2 zeta = fo.zeta, g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
+  lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
   ch.observe_n(proof + L.op_constants, 2 * (ncs + W));
   ch.observe_n(proof + L.op_zs, 2 * CH);
   ch.observe_n(proof + L.op_pp, 2 * CH * npp);
@@ -643,7 +726,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
   ch.observe_n(proof + L.op_zs_next, 2 * CH);
 
   // ---- K7b: final polynomial of the batched opening
-  alpha = ch.get_ext();
+  const gl2 alpha = fo.alpha = ch.get_ext();
   {
     const u32 total_polys = ncs + W + CH * (1 + npp) + CH * Q;
     const u32 h = (p.degree_bits + 1) / 2;
@@ -674,41 +757,38 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     launch_divide_finalize(s, a, c->fri_c[0].u(), c->fri_c[0].u() + n);
   }
   LCP2_HIP(ctx, hipGetLastError());
+  if (p.num_fri_layers) LCP2_TRY(fri_commit_layer(c, 0, 0, n, GL_GENERATOR, proof));
+  fo.phase = 2;
+  return LCP2_OK;
+}
 
-  // ---- K8: FRI commit phase
+int fri_open_finish(lcp2_circuit *c, u64 *proof) {
+  LCP2_STAGE_PROLOGUE
+  FriOpenState &fo = c->fo;
+  if (fo.phase != 2) return ctx->fail(LCP2_E_INVALID, "lcp2_fri_open_finish: call lcp2_fri_open_commit first");
+  fo.phase = 0;
+  HostChallenger &ch = fo.ch;
+  gl2 *fri_betas = fo.fri_betas;
+  std::vector<u64> &idx = fo.idx;
+  lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+
+  // ---- K8: FRI commit phase (layer 0 is committed already)
   u64 m = n;  // number of (possibly) non-zero coefficients; the zero padding to 8m is implicit
   u64 shift = GL_GENERATOR;
   int cur = 0;
-  {
-    for (u32 l = 0; l < p.num_fri_layers; l++) {
-      const u32 ab = p.fri_arity_bits[l], arity = 1u << ab;
-      u32 lgm = 0;
-      while ((1ull << lgm) < m) lgm++;
-      const u64 nvals = m << p.rate_bits, nleaves = nvals >> ab;
-      u64 *vals = c->fri_vals[l].u();
-      {
-        ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * nvals + 32.0 * nleaves);
-        // coset_fft of the zero-padded coefficients = 2^rate_bits coset transforms of the m coefficients; leaf order out
-        ntt.forward(c->fri_c[cur].u(), m, vals, nvals, lgm, 2, shift, p.rate_bits);
-        if (be.status) return be.status;
-        launch_hash_ext_leaves(s, vals, vals + nvals, arity, nleaves, c->fri_dig[l].u(), ctx->d_rc);
-        const auto &off = c->fri_level_off[l];
-        for (size_t k = 1; k < off.size(); k++)
-          launch_merkle_level(s, c->fri_dig[l].u() + 4 * off[k - 1], c->fri_dig[l].u() + 4 * off[k], nleaves >> k, ctx->d_rc);
-      }
-      LCP2_HIP(ctx, hipGetLastError());
-      LCP2_TRY(download(ctx, proof + L.fri_caps + l * L.capw, c->fri_dig[l].u() + 4 * c->fri_level_off[l].back(), L.capw * 8));
-      ch.observe_n(proof + L.fri_caps + l * L.capw, L.capw);
-      gl2 beta = ch.get_ext();
-      fri_betas[l] = beta;
-      {
-        ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * (m >> ab));
-        launch_fri_fold(s, c->fri_c[cur].u(), c->fri_c[cur].u() + m, c->fri_c[cur ^ 1].u(), c->fri_c[cur ^ 1].u() + (m >> ab), m >> ab, arity, beta.c0, beta.c1);
-      }
-      cur ^= 1;
-      m >>= ab;
-      shift = gl_pow(shift, arity);
+  for (u32 l = 0; l < p.num_fri_layers; l++) {
+    const u32 ab = p.fri_arity_bits[l], arity = 1u << ab;
+    if (l) LCP2_TRY(fri_commit_layer(c, l, cur, m, shift, proof));
+    ch.observe_n(proof + L.fri_caps + l * L.capw, L.capw);
+    gl2 beta = ch.get_ext();
+    fri_betas[l] = beta;
+    {
+      ProfScope ps(ctx, LCP2_K_FRI, 16.0 * m + 16.0 * (m >> ab));
+      launch_fri_fold(s, c->fri_c[cur].u(), c->fri_c[cur].u() + m, c->fri_c[cur ^ 1].u(), c->fri_c[cur ^ 1].u() + (m >> ab), m >> ab, arity, beta.c0, beta.c1);
     }
+    cur ^= 1;
+    m >>= ab;
+    shift = gl_pow(shift, arity);
   }
   if (m != L.final_len) return ctx->fail(LCP2_E_INVALID, "internal: final polynomial length mismatch");
   {
@@ -719,7 +799,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
   ch.observe_n(proof + L.final_poly, 2 * L.final_len);
 
   // ---- K9: proof of work, minimum witness
-  pow_witness = 0;
+  u64 pow_witness = 0;
   {
     PowArgs a{};
     ch.pow_state(a.state, a.pos);
@@ -738,7 +818,7 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     }
     pow_witness = res;
   }
-  proof[L.pow_witness] = pow_witness;
+  fo.pow_witness = proof[L.pow_witness] = pow_witness;
   ch.observe(pow_witness);
   {
     u64 resp = ch.get();
@@ -754,8 +834,8 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     u64 xi = x;
     for (u32 l = 0; l < p.num_fri_layers; l++) { xi >>= p.fri_arity_bits[l]; idx[(1 + l) * Qn + q] = xi; }
   }
-  // a sharded circuit answers the initial-tree part of the queries whose leaf it holds and leaves zeros for the others
-  // (its share of the proof); the FRI layers are replicated on every rank
+  // a sharded circuit answers the initial-tree and FRI-layer-0 parts of the queries whose leaf it holds and leaves zeros for
+  // the others (its share of the proof); the smaller FRI layers are replicated on every rank
   const u64 leaf0 = (u64)c->bf * n, nlocal = (u64)c->nblocks() * n;
   std::vector<u64> up(idx);
   std::vector<char> mine(Qn, 1);
@@ -763,10 +843,11 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
     mine[q] = idx[q] >= leaf0 && idx[q] < leaf0 + nlocal;
     up.push_back(mine[q] ? idx[q] - leaf0 : 0);
   }
+  for (u32 q = 0; q < Qn; q++) up.push_back(p.num_fri_layers ? up[idx.size() + q] >> p.fri_arity_bits[0] : 0);  // layer-0 leaf, local
   LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, up.data(), up.size() * 8, hipMemcpyHostToDevice, s));
   {
     u64 *d_idx = c->q_idx.u();
-    const u64 *d_idx_local = d_idx + idx.size();
+    const u64 *d_idx_local = d_idx + idx.size(), *d_idx_local0 = d_idx_local + Qn;
     u64 *buf = c->q_buf.u();
     size_t pos = 0;
     size_t o_leaf[4], o_sib[4], f_leaf[LCP2_MAX_FRI_LAYERS], f_sib[LCP2_MAX_FRI_LAYERS];
@@ -779,10 +860,12 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
       const u32 arity = 1u << p.fri_arity_bits[l];
       u64 nvals = N;  // values of layer l: N >> (arity bits of the layers before it)
       for (u32 k = 0; k < l; k++) nvals >>= p.fri_arity_bits[k];
+      if (l == 0) nvals = nlocal;
+      const u64 *d_leaf = l == 0 ? d_idx_local0 : d_idx + (1 + l) * Qn;
       f_leaf[l] = pos; pos += (size_t)Qn * 2 * arity;
       f_sib[l] = pos; pos += (size_t)Qn * L.q_step_sib[l] * 4;
-      launch_gather_ext_leaves(s, c->fri_vals[l].u(), c->fri_vals[l].u() + nvals, arity, d_idx + (1 + l) * Qn, Qn, buf + f_leaf[l]);
-      launch_gather_digests(s, c->fri_dig[l].u(), c->fri_d_level_off[l].u(), (u32)L.q_step_sib[l], d_idx + (1 + l) * Qn, Qn, buf + f_sib[l]);
+      launch_gather_ext_leaves(s, c->fri_vals[l].u(), c->fri_vals[l].u() + nvals, arity, d_leaf, Qn, buf + f_leaf[l]);
+      launch_gather_digests(s, c->fri_dig[l].u(), c->fri_d_level_off[l].u(), (u32)L.q_step_sib[l], d_leaf, Qn, buf + f_sib[l]);
     }
     LCP2_HIP(ctx, hipGetLastError());
     if (pos * 8 > c->q_buf.bytes) return ctx->fail(LCP2_E_INVALID, "internal: query workspace too small");
@@ -796,23 +879,35 @@ int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl
         memcpy(R + L.q_init_off[o] + nc, h.data() + o_sib[o] + (size_t)q * L.q_init_sib * 4, L.q_init_sib * 32);
       }
       for (u32 l = 0; l < p.num_fri_layers; l++) {
+        if (l == 0 && !mine[q]) continue;
         const u32 arity = 1u << p.fri_arity_bits[l];
         memcpy(R + L.q_step_off[l], h.data() + f_leaf[l] + (size_t)q * 2 * arity, 2 * arity * 8);
         memcpy(R + L.q_step_off[l] + 2 * arity, h.data() + f_sib[l] + (size_t)q * L.q_step_sib[l] * 4, L.q_step_sib[l] * 32);
       }
     }
   }
-  // Shares must SUM to the proof (RCCL has no bitwise reductions): the words every rank computes identically (openings,
-  // FRI caps and layers, final polynomial, PoW witness) are contributed by the rank that holds leaf block 0 only.
+  // Shares must SUM to the proof (RCCL has no bitwise reductions): the words every rank holds identically (openings,
+  // FRI caps, the smaller FRI layers, final polynomial, PoW witness) are contributed by the rank that holds leaf block 0 only.
   if (c->sharded() && c->bf != 0) {
     std::vector<u64> keep(proof + L.queries, proof + L.queries + (size_t)Qn * L.query_words);
     memset(proof + L.op_constants, 0, (L.total - L.op_constants) * 8);
-    for (u32 q = 0; q < Qn; q++) {
-      if (!mine[q]) continue;
-      const size_t init_words = L.q_step_off[0] ? L.q_step_off[0] : L.query_words;  // the four initial-tree openings come first
-      memcpy(proof + L.queries + (size_t)q * L.query_words, keep.data() + (size_t)q * L.query_words, init_words * 8);
-    }
+    const size_t own_words = p.num_fri_layers >= 2 ? L.q_step_off[1] : L.query_words;  // initial trees and FRI layer 0 come first
+    for (u32 q = 0; q < Qn; q++)
+      if (mine[q]) memcpy(proof + L.queries + (size_t)q * L.query_words, keep.data() + (size_t)q * L.query_words, own_words * 8);
   }
+  return LCP2_OK;
+}
+
+// the three phases back to back (a circuit that holds every leaf block)
+int stage_fri_open(lcp2_circuit *c, gl2 zeta, HostChallenger &ch, u64 *proof, gl2 &alpha, gl2 *fri_betas, u64 &pow_witness, std::vector<u64> &idx) {
+  if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: lcp2_fri_open_begin / _commit / _finish with their exchange steps");
+  FriOpenState &fo = c->fo;
+  fo.zeta = zeta; fo.ch = ch;
+  LCP2_TRY(fri_open_openings(c, proof));
+  LCP2_TRY(fri_open_commit(c, proof));
+  LCP2_TRY(fri_open_finish(c, proof));
+  ch = fo.ch; alpha = fo.alpha; pow_witness = fo.pow_witness; idx = fo.idx;
+  for (u32 l = 0; l < c->p.num_fri_layers; l++) fri_betas[l] = fo.fri_betas[l];
   return LCP2_OK;
 }
 }  // namespace
@@ -944,4 +1039,37 @@ extern "C" int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_chall
   LCP2_TRY(stage_fri_open(c, gl2_make(gl_canon(zeta[0]), gl_canon(zeta[1])), ch, (u64 *)proof, alpha, fri_betas, pow_witness, idx));
   ch.save((u64 *)chs->sponge, (u64 *)chs->input, chs->input_len, (u64 *)chs->output, chs->output_len);
   return LCP2_OK;
+}
+
+// the same stage in its three phases, for a coset-sharded proof (and for callers that want the exchange points)
+extern "C" int lcp2_fri_open_begin(lcp2_circuit *c, const uint64_t zeta[2], const lcp2_challenger *chs, uint64_t *proof) {
+  if (!c || !zeta || !chs || !proof) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (chs->input_len >= 8 || chs->output_len > 8) return LCP2_E_INVALID;
+  c->fo.phase = 0;
+  c->fo.ch.load((const u64 *)chs->sponge, (const u64 *)chs->input, chs->input_len, (const u64 *)chs->output, chs->output_len);
+  c->fo.zeta = gl2_make(gl_canon(zeta[0]), gl_canon(zeta[1]));
+  return fri_open_openings(c, (u64 *)proof);
+}
+extern "C" int lcp2_fri_open_commit(lcp2_circuit *c, uint64_t *proof) {
+  if (!c || !proof) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return fri_open_commit(c, (u64 *)proof);
+}
+extern "C" int lcp2_fri_open_finish(lcp2_circuit *c, lcp2_challenger *chs, uint64_t *proof) {
+  if (!c || !proof) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  LCP2_TRY(fri_open_finish(c, (u64 *)proof));
+  if (chs) c->fo.ch.save((u64 *)chs->sponge, (u64 *)chs->input, chs->input_len, (u64 *)chs->output, chs->output_len);
+  return LCP2_OK;
+}
+extern "C" int lcp2_proof_section(const lcp2_circuit *c, int section, size_t *first_word, size_t *num_words) {
+  if (!c || !first_word || !num_words) return LCP2_E_INVALID;
+  const ProofLayout L(c->p);
+  switch (section) {
+    case LCP2_SECTION_OPENINGS: *first_word = L.op_constants; *num_words = L.fri_caps - L.op_constants; return LCP2_OK;
+    case LCP2_SECTION_FRI_CAP0: *first_word = L.fri_caps; *num_words = c->p.num_fri_layers ? L.capw : 0; return LCP2_OK;
+    case LCP2_SECTION_AFTER_CAPS: *first_word = L.op_constants; *num_words = L.total - L.op_constants; return LCP2_OK;
+  }
+  return LCP2_E_INVALID;
 }

@@ -111,6 +111,8 @@ class ShardedProver:
                        iNTT) and the coefficients are all-gathered: the commitment's "column transpose" 
         caps, proof    shares (own entries at their global position, zeros elsewhere): SUM all-reduce of 512-byte caps and of
                        the 140 KB proof array (uint64 wrap-around; RCCL has no bitwise reductions)
+        openings, FRI  a rank evaluates its share of the columns at zeta and commits its leaf blocks of FRI layer 0 (folding is in
+                       coefficient form: no FRI values cross the ranks); shares of the 4 KB of openings and of the layer-0 cap
         quotient       each challenge plane of the value buffer is completed by an in-place all-gather of the ranks' contiguous
                        leaf blocks (537 MB in total at n = 2^22, each byte crosses the fabric once)
     `comm` supplies the collectives, so that the same orchestration runs over torch.distributed (TorchComm: "nccl" = RCCL on
@@ -195,11 +197,18 @@ class ShardedProver:
         proof[2 * capw:3 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[2 * capw:3 * capw])
         zeta = ch.get(2)
-        caps = proof[:3 * capw].copy()
-        d.fri_open(zeta, ch.state, proof)  # writes the words after the caps: this rank's share of them
-        proof[:3 * capw] = 0
-        proof = (yield ("sum_host", proof))
-        proof[:3 * capw] = caps
+        # the opening stage in its three phases: this rank's columns of the openings, then its leaf blocks of FRI layer 0, then
+        # the rest; what the phases leave in the proof array is this rank's share of the section
+        d.fri_open_begin(zeta, ch.state, proof)
+        lo, cnt = d.proof_section(b.SECTION_OPENINGS)
+        proof[lo:lo + cnt] = yield ("sum_host", proof[lo:lo + cnt])
+        d.fri_open_commit(proof)
+        lo, cnt = d.proof_section(b.SECTION_FRI_CAP0)
+        if cnt:
+            proof[lo:lo + cnt] = yield ("sum_host", proof[lo:lo + cnt])
+        d.fri_open_finish(proof)
+        lo, cnt = d.proof_section(b.SECTION_AFTER_CAPS)
+        proof[lo:lo + cnt] = yield ("sum_host", proof[lo:lo + cnt])
         self.proof = proof
         return
 

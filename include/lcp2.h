@@ -290,6 +290,20 @@ typedef struct {
  * front of them are the caller's). */
 int lcp2_fri_open(lcp2_circuit *c, const uint64_t zeta[2], lcp2_challenger *ch, uint64_t *proof);
 
+/* lcp2_fri_open in its three phases (lcp2_fri_open is their composition, one code path), for callers that need the points
+ * between them - a coset-sharded proof exchanges shares there:
+ *   lcp2_fri_open_begin    OpeningSet::new: the openings at zeta and g*zeta                    -> LCP2_SECTION_OPENINGS
+ *   lcp2_fri_open_commit   observes the openings, draws alpha, composes the final polynomial of the batch and commits
+ *                          FRI layer 0 (the 8n-point LDE, its leaves and Merkle levels)         -> LCP2_SECTION_FRI_CAP0
+ *   lcp2_fri_open_finish   the remaining FRI layers, final polynomial, proof of work, query answers; ch (nullable): the
+ *                          challenger state after the query indices
+ * lcp2_proof_section gives the word range of a section inside the proof array. */
+enum { LCP2_SECTION_OPENINGS = 0, LCP2_SECTION_FRI_CAP0 = 1, LCP2_SECTION_AFTER_CAPS = 2 };
+int lcp2_fri_open_begin(lcp2_circuit *c, const uint64_t zeta[2], const lcp2_challenger *ch, uint64_t *proof);
+int lcp2_fri_open_commit(lcp2_circuit *c, uint64_t *proof);
+int lcp2_fri_open_finish(lcp2_circuit *c, lcp2_challenger *ch, uint64_t *proof);
+int lcp2_proof_section(const lcp2_circuit *c, int section, size_t *first_word, size_t *num_words);
+
 /* host-side transcript helpers for callers that do not bring their own Challenger / PoseidonHash (no device work) */
 void lcp2_challenger_init(lcp2_challenger *ch);
 int lcp2_challenger_observe(lcp2_challenger *ch, const uint64_t *values, size_t count);
@@ -299,20 +313,23 @@ int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* 
 /* ---- one proof sharded over the GPUs of a node by LDE coset (BASELINE configs[3]).
  * A sharded circuit holds the leaf blocks [block_first, block_first + block_count) of every LDE and Merkle tree
  * (block_count a power of two dividing 2^rate_bits, block_first aligned to it, cap_height >= rate_bits so that a block is
- * whole cap subtrees: no cross-GPU hashing).  Every rank gets the whole witness and runs the same call sequence as the
- * seams above; what a rank returns is its SHARE of the result - its own cap entries / query answers at their global
- * position, zeros elsewhere; the parts of lcp2_fri_open's output that every rank computes identically come from the rank
- * holding block 0 only - so one SUM all-reduce (uint64 wrap-around; RCCL has no bitwise reductions) of each cap and of
- * the proof words lcp2_fri_open wrote assembles the result.  The bulk exchanges are (1) the witness: the ranks may hold
+ * whole cap subtrees: no cross-GPU hashing).  Every rank runs the same call sequence as the seams above; what a rank returns
+ * is its SHARE of the result - its own cap entries / openings / query answers at their global position, zeros elsewhere; the
+ * proof words every rank holds identically come from the rank holding block 0 only - so one SUM all-reduce (uint64 wrap-around;
+ * RCCL has no bitwise reductions) of a share assembles the result.  The bulk exchanges are (1) the witness: the ranks may hold
  * column shards, all-gather the values, transform their own columns and all-gather the coefficients (lcp2_commit_wires_coeffs);
  * (2) the quotient values (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer - per challenge
  * plane they are one contiguous run at offset block_first * n, in rank order - so an in-place all-gather of each plane
  * completes the buffer (a SUM all-reduce works too: the rest is zeros); then every rank calls lcp2_quotient_commit.
+ * In the opening stage a rank evaluates its share of the columns of every batch (it holds all coefficients) and commits its
+ * own leaf blocks of FRI layer 0; folding is done in coefficient form, so no FRI values cross the ranks, and the smaller
+ * layers are computed by every rank.
  * Order per proof:
  *   lcp2_commit_wires[_coeffs] -> sum caps -> lcp2_perm_zs -> sum caps -> lcp2_quotient_values -> all-gather planes ->
- *   lcp2_quotient_commit -> sum caps -> lcp2_fri_open -> sum the words from the openings on.
+ *   lcp2_quotient_commit -> sum caps -> lcp2_fri_open_begin -> sum LCP2_SECTION_OPENINGS -> lcp2_fri_open_commit ->
+ *   sum LCP2_SECTION_FRI_CAP0 -> lcp2_fri_open_finish -> sum LCP2_SECTION_AFTER_CAPS.
  * At build: lcp2_circuit_create_sharded, lcp2_circuit_digest (cap share; digest not valid yet), sum the cap,
- * lcp2_circuit_set_constants_cap.  lcp2_prove / lcp2_quotient refuse a sharded circuit. */
+ * lcp2_circuit_set_constants_cap.  lcp2_prove / lcp2_quotient / lcp2_fri_open refuse a sharded circuit. */
 int lcp2_circuit_create_sharded(lcp2_ctx *ctx, const lcp2_circuit_desc *desc, uint32_t block_first, uint32_t block_count,
                                 lcp2_circuit **out);
 int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap);

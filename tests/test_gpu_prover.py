@@ -311,6 +311,24 @@ def test_staged_seams_compose_to_prove(gpu_ctx, oracle):
     proof2[:3 * capw] = proof[:3 * capw]
     data.fri_open(zeta, st2, proof2)
     assert (proof2 == proof).all() and list(st2.sponge) == list(st.sponge) and list(st.sponge) != [int(v) for v in t.s]
+    # the same stage phase by phase (the exchange points of a sharded proof): identical words, identical final state;
+    # a phase out of order is refused
+    st3 = t.state(m)
+    proof3 = np.zeros_like(proof)
+    proof3[:3 * capw] = proof[:3 * capw]
+    with pytest.raises(m.Lcp2Error):
+        data.fri_open_commit(proof3)
+    data.fri_open_begin(zeta, st3, proof3)
+    lo, cnt = data.proof_section(m.binding.SECTION_OPENINGS)
+    assert (proof3[lo:lo + cnt] == proof[lo:lo + cnt]).all() and (proof3[lo + cnt:] == 0).all()
+    with pytest.raises(m.Lcp2Error):
+        data.fri_open_finish(proof3)
+    data.fri_open_commit(proof3)
+    lo, cnt = data.proof_section(m.binding.SECTION_FRI_CAP0)
+    assert cnt == capw and (proof3[lo:lo + cnt] == proof[lo:lo + cnt]).all()
+    data.fri_open_finish(proof3, st3)
+    assert (proof3 == proof).all() and list(st3.sponge) == list(st.sponge)
+    assert data.proof_section(m.binding.SECTION_AFTER_CAPS) == (3 * capw, data.proof_words - 3 * capw)
     data.close()
 
 

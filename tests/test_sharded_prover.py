@@ -207,10 +207,20 @@ class FakeData:
             self.qbuf[32 * c + 16 * self.rank:32 * c + 16 * self.rank + 16] = np.arange(16, dtype=np.uint64) + np.uint64(int(alphas[0]) % 1000 + 50 * c)
     def quotient_buffer(self): return (self.qbuf.ctypes.data, self.qbuf.size)
     def quotient_commit(self): return self._share(3 + int(self.qbuf.sum() % 5))  # depends on the exchanged buffer
-    def fri_open(self, zeta, state, proof):
+    # proof body (after the three caps): [0, 8) openings, [8, 20) FRI cap of layer 0 + replicated words, [20, 40) query answers
+    def proof_section(self, which): return {0: (192, 8), 1: (200, 4), 2: (192, 40)}[which]
+    def fri_open_begin(self, zeta, state, proof):
+        self.z = int(zeta[0]) % 97
+        proof[192 + 4 * self.rank:196 + 4 * self.rank] = np.arange(4, dtype=np.uint64) + np.uint64(4 * self.rank + self.z)  # own columns
+    def fri_open_commit(self, proof):
+        assert (proof[192:200] == np.arange(8, dtype=np.uint64) + np.uint64(self.z)).all()        # the openings arrived complete
+        proof[200 + 2 * self.rank:202 + 2 * self.rank] = np.uint64(8 + self.z) + np.arange(2, dtype=np.uint64) + np.uint64(2 * self.rank)
+    def fri_open_finish(self, proof):
+        assert (proof[200:204] == np.arange(4, dtype=np.uint64) + np.uint64(8 + self.z)).all()    # and so did the layer-0 cap
         body = proof[3 * 64:]
-        if self.rank == 0: body[:20] = np.arange(20, dtype=np.uint64) + np.uint64(int(zeta[0]) % 97)   # replicated part
-        body[20 + 10 * self.rank:30 + 10 * self.rank] = np.uint64(555 + self.rank)                     # this rank's query answers
+        if self.rank == 0: body[12:20] = np.arange(8, dtype=np.uint64) + np.uint64(12 + self.z)   # replicated part
+        else: body[:20] = 0                                                                       # ... from rank 0 only
+        body[20 + 10 * self.rank:30 + 10 * self.rank] = np.uint64(555 + self.rank)                # this rank's query answers
 class GlooComm(m.parallel.TorchComm):
     def all_gather_device(self, ptr, total_words, words_per_rank):  # the "device" buffer of the stand-in is a numpy array
         import torch

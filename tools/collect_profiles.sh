@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): every measurement DESIGN.md / bench.py quote for one round, into $1 (under gpurun_out/).
 #   rocprofv3 kernel trace + stats of bench.py, FETCH_SIZE and WRITE_SIZE PMC passes (separate, as MI355X_MICROARCH.md prescribes),
-#   SQ counters of a 2^20 proof, kernel traces of the real light-client step, the plain bench line, the instruction-rate ubench.
+#   SQ counters of a 2^22 proof, kernel traces of the real light-client step, the plain bench line, the instruction-rate ubench,
+#   the per-rank compute of a sharded proof (one rank at a time) and the sharded code path over a 1-rank RCCL group.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=$1
 mkdir -p $out
@@ -12,6 +13,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/sq -o sq -- python3 tools/prof_prove.py 22 1 > $out/sq.log 2>&1 && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/lc -o lc -- ./examples/lc_prover tmp_fixtures/u633.json tmp_fixtures/u634.json --repeat 2 > $out/lc.log 2>&1 && \
 ./tools/ubench/int_rates > $out/ubench.txt 2>&1 && \
+for rw in 1/2 2/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal.log || exit 1; done && \
+python3 bench.py --force-sharded --no-cpu-baseline --no-real-gadgets > $out/bench_force_sharded.json 2> $out/bench_force_sharded.err && \
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "collect rc=$?"
 find $out -name "*.csv" | head -30

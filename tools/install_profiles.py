@@ -27,6 +27,10 @@ json_line(f"{src}/bench_under_pmc_fetch.json", f"{p}/{tag}_bench_under_pmc_fetch
 shutil.copy(f"{src}/kt/kt_kernel_stats.csv", f"{p}/{tag}_full_proof_kernel_stats.csv")
 shutil.copy(f"{src}/lc/lc_kernel_stats.csv", f"{p}/{tag}_lc_step_kernel_stats.csv")
 shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
+if os.path.exists(f"{src}/sharded_rehearsal.log"):
+    shutil.copy(f"{src}/sharded_rehearsal.log", f"{p}/{tag}_sharded_rehearsal.log")
+if os.path.exists(f"{src}/bench_force_sharded.json"):
+    json_line(f"{src}/bench_force_sharded.json", f"{p}/{tag}_bench_force_sharded.json")
 for which in ("fetch", "write"):
     # keep the per-dispatch counter rows of the library's kernels only (the full csv is tens of MB)
     rows = list(csv.DictReader(open(f"{src}/{which}/{which}_counter_collection.csv")))

@@ -4,8 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_proof_demo.py [--degree-bits 22]
 
 Every rank builds the same synthetic circuit and witness (same seed), holds 8/N leaf blocks of every LDE / Merkle tree and
-proves through eth-lc-plonky2_amd/parallel.py::ShardedProver: four 512-byte sum all-reduces, one sum all-reduce of the proof
-array and one bulk all-reduce of the quotient values (2 * 8n words) over RCCL.  Rank 0 verifies the assembled proof and
+proves through eth-lc-plonky2_amd/parallel.py::ShardedProver: in-place all-gathers of the witness values, the coefficients and
+the quotient planes, and small sum all-reduces of the shares (caps, openings, the proof array) over RCCL.  Rank 0 verifies the assembled proof and
 prints the wall time per proof.  With N = 1 the same code path runs with one rank holding all 8 blocks (the only case a
 one-GPU box can run; the multi-rank data flow is covered by tests/test_sharded_prover.py with the ranks in lockstep on
 one GPU)."""
@@ -21,14 +21,36 @@ class _Solo:  # N = 1: the collectives are the identity
     def sum_host(self, a):
         return a
 
-    def sum_device(self, ptr, words):
+    def all_gather_device(self, ptr, total_words, words_per_rank):
         pass
+
+
+class _Rehearsal(_Solo):
+    """rank R of W alone on one GPU: the collectives are the identity except the first all-gather (the witness values), which is
+    filled from the whole witness - a rank checks the witness it proves, so the values must be the real ones.  The time spent in
+    here is not the rank's compute."""
+
+    def __init__(self, m, ctx, d_wires, num_wires, n, world):
+        self.m, self.ctx, self.d_wires, self.n, self.calls, self.seconds = m, ctx, d_wires, n, 0, 0.0
+        self.shards = m.parallel.column_shards(num_wires, world)
+
+    def all_gather_device(self, ptr, total_words, words_per_rank):
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if self.calls == 0:
+            for r, (s, e) in enumerate(self.shards):
+                self.ctx.buffer_copy(ptr + 8 * r * words_per_rank, self.d_wires.data_ptr() + 8 * s * self.n, (e - s) * self.n)
+        self.calls += 1
+        torch.cuda.synchronize()
+        self.seconds += time.time() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--degree-bits", type=int, default=22)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--sharded-columns", action="store_true", help="the witness arrives column-sharded (all-gather of values and coefficients)")
     ap.add_argument("--rehearse", default="", help="R/W: time the compute of rank R of W on this one GPU (collectives replaced by "
                     "the identity, so the transcript is not the real one and the proof is not verified)")
     a = ap.parse_args()
@@ -52,18 +74,30 @@ def main():
     prover.finish_build()
     build_s = time.time() - t0
     d_wires = torch.from_numpy(wires.view("int64")).cuda()  # witness resident in HBM, as in bench.py
+    n = 1 << a.degree_bits
+    if rehearse and a.sharded_columns:
+        prover.comm = comm = _Rehearsal(m, ctx, d_wires, params.num_wires, n, world)
+    first, end = prover.column_shard()
+    mine = d_wires[first:end].contiguous() if a.sharded_columns else d_wires
     times = []
+    ctx.prof_enable(True)
     for _ in range(a.reps):
         if world > 1 and not rehearse:
             dist.barrier()
+        if isinstance(comm, _Rehearsal):
+            comm.calls, comm.seconds = 0, 0.0
+        ctx.prof_reset()
         torch.cuda.synchronize()
         t0 = time.time()
-        proof = prover.prove(d_wires.data_ptr(), pis, mem=m.MEM_DEVICE)
+        proof = prover.prove(mine.data_ptr(), pis, mem=m.MEM_DEVICE, sharded_columns=a.sharded_columns)
         torch.cuda.synchronize()
-        times.append(time.time() - t0)
+        times.append(time.time() - t0 - (comm.seconds if isinstance(comm, _Rehearsal) else 0.0))
+    fam = ", ".join("%s %.1f" % (k, v["ms"]) for k, v in ctx.prof_get().items() if v["ms"] > 0.05)
     if rehearse:
-        print("rehearsal of rank %d of %d, degree_bits %d: build %.2f s, per-rank compute of a sharded proof %s ms (exchanges excluded)"
-              % (rank, world, a.degree_bits, build_s, ", ".join("%.1f" % (1e3 * t) for t in times)))
+        print("rehearsal of rank %d of %d, degree_bits %d%s: build %.2f s, per-rank compute of a sharded proof %s ms (exchanges excluded); "
+              "kernel families of the last proof (ms): %s"
+              % (rank, world, a.degree_bits, ", column-sharded witness" if a.sharded_columns else "", build_s,
+                 ", ".join("%.1f" % (1e3 * t) for t in times), fam))
         return
     if rank == 0:
         digest, _ = prover.data.digest()
