@@ -26,7 +26,7 @@
 //
 // Inside a slab the B stages of the group run as REGISTER STEPS of r <= 4 stages: a thread pulls the 2^r
 // elements that differ in r consecutive index bits out of LDS, runs the 2^r-point transform in registers
-// (constant twiddles w_16^k held in SGPRs), applies the step twiddle w_{N'}^(m * bitrev(j)) (N' = size of
+// (the constant twiddles w_16^k are powers of two: shifts), applies the step twiddle w_{N'}^(m * bitrev(j)) (N' = size of
 // the sub-transform the step starts, m = index bits below the step) and puts them back: 13 stages cost
 // 4 LDS round trips and barriers instead of 13, and the index arithmetic is paid once per 2^r elements.
 // LDS words are padded by one per 16 (lds_phys) so that the bottom step, where each thread owns 16
@@ -65,7 +65,6 @@ struct NttPassParams {
   u32 out_block_base;                 // leaf block that sits at offset 0 of `out` (a rank holds blocks [base, base + count))
   u32 L, S, B, g_lo;                  // slab bits, run bits, group bits, bits below the group
   const u64 *group_tw;                // w_{2^B}^e (or its inverse), e < 2^B: step twiddles
-  u64 wr[8];                          // w_16^k (or inverse), k < 8: constant twiddles of the register transforms
   u32 xcd_group;                      // LDE first pass: the 2^zbits coset transforms of one slab run back to back on one XCD (kernels_ntt.hip)
   u32 nsteps;
   u32 step_plan;                      // stages per register step, 4 bits each, listed from the top bits of the group down
@@ -80,43 +79,44 @@ LCP2_HD u32 lds_phys(u32 i) { return i + (i >> 4); }
 LCP2_HD u32 ntt_lds_words(u32 L) { return (1u << L) + ((1u << L) >> 4) + 1; }
 
 // The 16th roots of unity of the field are powers of two: 2 has order 192 (2^96 = -1) and plonky2's w_16 (the generator's
-// power) is 2^156 = -2^60, so w_16^k = +-2^s for every k.  Where s < 64 the twiddle multiply of a register butterfly is a
-// shift-reduce (gl_shl, ~13 instructions against 21 for a general multiply) and the sign goes into the order of the
-// subtraction; 2^72 and 2^84 (k = 3, 6 forward; k = 2, 5 inverse) overflow the 128-bit shift and stay general multiplies by
-// the constant wr[k].  tests/emu and the GPU parity tests compare the transforms with the oracle's textbook radix-2 NTT.
+// power) is 2^156 = -2^60, so w_16^k = +-2^s with s < 96 for every k: the twiddle multiply of a register butterfly is a
+// shift-reduce (gl_shl: 10-12 instructions against 21 for a general multiply) and the sign goes into the order of the
+// subtraction.  tests/emu and the GPU parity tests compare the transforms with the oracle's textbook radix-2 NTT.
 //   forward  w^k : k=1 -2^60  k=2 -2^24  k=3 2^84   k=4  2^48  k=5  2^12  k=6 -2^72  k=7 -2^36
 //   inverse w^-k : k=1  2^36  k=2  2^72  k=3 -2^12  k=4 -2^48  k=5 -2^84  k=6  2^24  k=7  2^60
 // (a - b) * w_16^k
-LCP2_HD u64 ntt_dif_twiddle(u64 a, u64 b, u32 k, const u64 *wr) {
+LCP2_HD u64 ntt_dif_twiddle(u64 a, u64 b, u32 k) {
   switch (k) {
     case 1: return gl_shl<60>(gl_sub(b, a));
     case 2: return gl_shl<24>(gl_sub(b, a));
+    case 3: return gl_shl<84>(gl_sub(a, b));
     case 4: return gl_shl<48>(gl_sub(a, b));
     case 5: return gl_shl<12>(gl_sub(a, b));
-    case 7: return gl_shl<36>(gl_sub(b, a));
-    default: return gl_mul(gl_sub(a, b), wr[k]);
+    case 6: return gl_shl<72>(gl_sub(b, a));
+    default: return gl_shl<36>(gl_sub(b, a));
   }
 }
 // (a + x w_16^-k, a - x w_16^-k)
-LCP2_HD void ntt_dit_butterfly(u64 a, u64 x, u32 k, const u64 *wr_inv, u64 &sum, u64 &diff) {
+LCP2_HD void ntt_dit_butterfly(u64 a, u64 x, u32 k, u64 &sum, u64 &diff) {
   u64 b;
   bool neg = false;
   switch (k) {
     case 1: b = gl_shl<36>(x); break;
+    case 2: b = gl_shl<72>(x); break;
     case 3: b = gl_shl<12>(x); neg = true; break;
     case 4: b = gl_shl<48>(x); neg = true; break;
+    case 5: b = gl_shl<84>(x); neg = true; break;
     case 6: b = gl_shl<24>(x); break;
-    case 7: b = gl_shl<60>(x); break;
-    default: b = gl_mul(x, wr_inv[k]); break;
+    default: b = gl_shl<60>(x); break;
   }
   sum = neg ? gl_sub(a, b) : gl_add(a, b);
   diff = neg ? gl_add(a, b) : gl_sub(a, b);
 }
 
-// 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out (wr[k] = w_16^k); dit: bit-reversed in ->
-// natural out (wr[k] = w_16^-k).
+// 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out; dit: bit-reversed in ->
+// natural out; the constant twiddles w_16^(+-k) are the shifts above.
 template <u32 RB>
-LCP2_HD void ntt_reg_dif(u64 *x, const u64 *wr) {
+LCP2_HD void ntt_reg_dif(u64 *x) {
   constexpr u32 R = 1u << RB;
 #pragma unroll
   for (u32 s = 0; s < RB; s++) {
@@ -126,12 +126,12 @@ LCP2_HD void ntt_reg_dif(u64 *x, const u64 *wr) {
       const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
       const u64 a = x[i0], b = x[i1];
       x[i0] = gl_add(a, b);
-      x[i1] = i ? ntt_dif_twiddle(a, b, i * (8 / half), wr) : gl_sub(a, b);
+      x[i1] = i ? ntt_dif_twiddle(a, b, i * (8 / half)) : gl_sub(a, b);
     }
   }
 }
 template <u32 RB>
-LCP2_HD void ntt_reg_dit(u64 *x, const u64 *wr) {
+LCP2_HD void ntt_reg_dit(u64 *x) {
   constexpr u32 R = 1u << RB;
 #pragma unroll
   for (u32 s = RB; s-- > 0;) {
@@ -141,7 +141,7 @@ LCP2_HD void ntt_reg_dit(u64 *x, const u64 *wr) {
       const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
       const u64 a = x[i0];
       if (i) {
-        ntt_dit_butterfly(a, x[i1], i * (8 / half), wr, x[i0], x[i1]);
+        ntt_dit_butterfly(a, x[i1], i * (8 / half), x[i0], x[i1]);
       } else {
         const u64 b = x[i1];
         x[i0] = gl_add(a, b);
@@ -189,17 +189,48 @@ struct NttPass {
     return two_level(p.tw, l * k1);
   }
 
-  // All three phases move NTT_BATCH elements per thread at a time with the loads issued back to back before any
-  // of them is used: with runtime trip counts the compiler otherwise serialises one HBM / LDS round trip per element.
+  // The load and store phases move NTT_BATCH elements per thread at a time with the loads issued back to back before any of them
+  // is used: with runtime trip counts the compiler otherwise serialises one HBM / LDS round trip per element.
+  //
+  // Thread tid owns the local indices i_k = tid + k * nthr.  When nthr is a multiple of 2^S (and of 16) the run offset of i_k
+  // and its LDS padding phase do not depend on k, so the global index, the index into a one-level factor table (which is
+  // indexed like the data) and the LDS word all advance by constants: one address computation per thread instead of a dozen
+  // shifts and masks per element.  Slabs that the threads do not tile evenly (small transforms) take the element-wise path.
+  LCP2_HD bool strided_walk(u32 nthr) const {
+    return p.S + p.B == p.L && (nthr & ((1u << p.S) - 1)) == 0 && (nthr & 15) == 0 && ((1u << p.L) % (nthr * NTT_BATCH)) == 0;
+  }
   template <bool INV>
   LCP2_HD void load(u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col, u32 z) const {
     const u64 *src = p.in + (u64)col * p.in_col_stride + (u64)z * p.in_z_stride;
     const u32 n = 1u << p.L;
+    // one-level factor tables are plain loads: issue them with the data (a two-level factor costs a multiply and waits)
+    const bool factor = INV ? p.g_lo != 0 : p.scale_mode != 0;
+    const bool early = factor && (INV ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT));
+    if (strided_walk(nthr)) {
+      const u64 g0 = global_index(wg, tid), gs = (u64)(nthr >> p.S) << p.g_lo;
+      const u32 ph0 = lds_phys(tid), ps = nthr + (nthr >> 4);
+      const u64 *fac = nullptr;
+      if (early) fac = INV ? p.tw.lo + (((u64)((tid >> p.S) & ((1u << p.B) - 1)) << p.g_lo) | low_bits(wg, tid)) : p.sc.lo + (u64)z * p.sc_lo_z_stride + g0;
+      for (u32 k0 = 0; k0 < n / nthr; k0 += NTT_BATCH) {
+        u64 v[NTT_BATCH], f[NTT_BATCH];
+#pragma unroll
+        for (u32 j = 0; j < NTT_BATCH; j++) {
+          v[j] = src[g0 + (k0 + j) * gs];
+          if (early) f[j] = fac[(k0 + j) * gs];
+        }
+#pragma unroll
+        for (u32 j = 0; j < NTT_BATCH; j++) {
+          const u32 i = tid + (k0 + j) * nthr;
+          u64 x;  // the multiply takes any u64; without one the element is made canonical here
+          if (factor) x = gl_mul(v[j], early ? f[j] : (INV ? group_twiddle(wg, i) : scale_at(g0 + (k0 + j) * gs, z)));
+          else x = gl_canon(v[j]);
+          lds[ph0 + (k0 + j) * ps] = x;
+        }
+      }
+      return;
+    }
     for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
       u64 g[NTT_BATCH], v[NTT_BATCH], f[NTT_BATCH];
-      // one-level factor tables are plain loads: issue them with the data (a two-level factor costs a multiply and waits)
-      const bool factor = INV ? p.g_lo != 0 : p.scale_mode != 0;
-      const bool early = factor && (INV ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT));
 #pragma unroll
       for (u32 j = 0; j < NTT_BATCH; j++) {
         u32 i = i0 + j * nthr;
@@ -220,25 +251,31 @@ struct NttPass {
   }
 
   // Register step over the RB group bits whose top one is kb_top (group-relative): see the header comment.
-  template <bool INV, u32 RB>
+  // PC: the local bit position P of the step's lowest bit when it is known at compile time (-1: runtime).  For P >= 4 the padded
+  // LDS word of element j is word(base) + j * (2^P + 2^(P-4)), for the bottom step (P = 0, 16 elements) word(base) + j: with
+  // PC given these are immediate offsets of the ds instructions instead of three address instructions per access.
+  template <bool INV, u32 RB, int PC>
   LCP2_HD void step_r(u64 *lds, u32 tid, u32 nthr, u32 kb_top) const {
     constexpr u32 R = 1u << RB;
-    const u32 mbits = kb_top + 1 - RB;          // group bits below the step
-    const u32 P = p.S + mbits;                  // local bit position of the step's lowest bit
+    const u32 mbits = kb_top + 1 - RB;                      // group bits below the step
+    const u32 P = PC >= 0 ? (u32)PC : p.S + mbits;          // local bit position of the step's lowest bit
     const u32 ngroups = 1u << (p.L - RB);
-    const u32 tw_shift = p.B - kb_top - 1;      // w_{N'} = w_{2^B}^(2^tw_shift)
+    const u32 tw_shift = p.B - kb_top - 1;                  // w_{N'} = w_{2^B}^(2^tw_shift)
+    const bool linear = P >= 4 || (P == 0 && RB == 4);
+    const u32 pstride = P >= 4 ? (1u << P) + (1u << (P - 4)) : 1u;
     for (u32 g = tid; g < ngroups; g += nthr) {
       const u32 base = ((g >> P) << (P + RB)) | (g & ((1u << P) - 1));
       const u32 m = (base >> p.S) & ((1u << mbits) - 1);
+      const u32 pb = lds_phys(base);
       u64 x[R], tw[R];
 #pragma unroll
-      for (u32 j = 0; j < R; j++) x[j] = lds[lds_phys(base | (j << P))];
+      for (u32 j = 0; j < R; j++) x[j] = lds[linear ? pb + j * pstride : lds_phys(base | (j << P))];
       if (mbits) {
 #pragma unroll
         for (u32 j = 1; j < R; j++) tw[j] = p.group_tw[(u64)(m * bitrev32(j, RB)) << tw_shift];
       }
       if (!INV) {
-        ntt_reg_dif<RB>(x, p.wr);
+        ntt_reg_dif<RB>(x);
         if (mbits) {
 #pragma unroll
           for (u32 j = 1; j < R; j++) x[j] = gl_mul(x[j], tw[j]);
@@ -248,10 +285,10 @@ struct NttPass {
 #pragma unroll
           for (u32 j = 1; j < R; j++) x[j] = gl_mul(x[j], tw[j]);
         }
-        ntt_reg_dit<RB>(x, p.wr);
+        ntt_reg_dit<RB>(x);
       }
 #pragma unroll
-      for (u32 j = 0; j < R; j++) lds[lds_phys(base | (j << P))] = x[j];
+      for (u32 j = 0; j < R; j++) lds[linear ? pb + j * pstride : lds_phys(base | (j << P))] = x[j];
     }
   }
   // step si of the pass in execution order (forward: from the top bits down; inverse: from the bottom up)
@@ -261,11 +298,17 @@ struct NttPass {
     u32 above = 0;
     for (u32 i = 0; i < idx; i++) above += (p.step_plan >> (4 * i)) & 15;
     const u32 kb_top = p.B - 1 - above;
-    switch ((p.step_plan >> (4 * idx)) & 15) {
-      case 1: step_r<INV, 1>(lds, tid, nthr, kb_top); break;
-      case 2: step_r<INV, 2>(lds, tid, nthr, kb_top); break;
-      case 3: step_r<INV, 3>(lds, tid, nthr, kb_top); break;
-      default: step_r<INV, 4>(lds, tid, nthr, kb_top); break;
+    const u32 rb = (p.step_plan >> (4 * idx)) & 15, P = p.S + kb_top + 1 - rb;
+    // the steps of the 2^13-element slabs of a large transform (3 + 3 + 3 + 4 contiguous, 3 + 3 + 3 strided over 16-element runs)
+    if (rb == 3 && P == 4) return step_r<INV, 3, 4>(lds, tid, nthr, kb_top);
+    if (rb == 3 && P == 7) return step_r<INV, 3, 7>(lds, tid, nthr, kb_top);
+    if (rb == 3 && P == 10) return step_r<INV, 3, 10>(lds, tid, nthr, kb_top);
+    if (rb == 4 && P == 0) return step_r<INV, 4, 0>(lds, tid, nthr, kb_top);
+    switch (rb) {
+      case 1: step_r<INV, 1, -1>(lds, tid, nthr, kb_top); break;
+      case 2: step_r<INV, 2, -1>(lds, tid, nthr, kb_top); break;
+      case 3: step_r<INV, 3, -1>(lds, tid, nthr, kb_top); break;
+      default: step_r<INV, 4, -1>(lds, tid, nthr, kb_top); break;
     }
   }
 
@@ -273,6 +316,27 @@ struct NttPass {
   LCP2_HD void store(const u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col, u32 z) const {
     u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)(bitrev32(z, p.zbits) - p.out_block_base) * p.out_z_stride;
     const u32 n = 1u << p.L;
+    const bool scaled = INV ? p.scale_mode != 0 : p.g_lo != 0;
+    if (strided_walk(nthr)) {
+      const u64 g0 = global_index(wg, tid), gs = (u64)(nthr >> p.S) << p.g_lo;
+      const u32 ph0 = lds_phys(tid), ps = nthr + (nthr >> 4);
+      const bool direct = scaled && (INV ? (p.scale_mode == 2 && p.sc.h == NTT_DIRECT) : p.tw.h == NTT_DIRECT);
+      const u64 *fac = nullptr;
+      if (direct) fac = INV ? p.sc.lo + (u64)z * p.sc_lo_z_stride + g0 : p.tw.lo + (((u64)((tid >> p.S) & ((1u << p.B) - 1)) << p.g_lo) | low_bits(wg, tid));
+      for (u32 k0 = 0; k0 < n / nthr; k0 += NTT_BATCH) {
+        u64 v[NTT_BATCH], tw[NTT_BATCH];
+#pragma unroll
+        for (u32 j = 0; j < NTT_BATCH; j++) {
+          v[j] = lds[ph0 + (k0 + j) * ps];
+          tw[j] = 1;
+          if (direct) tw[j] = fac[(k0 + j) * gs];
+          else if (scaled) tw[j] = INV ? scale_at(g0 + (k0 + j) * gs, z) : group_twiddle(wg, tid + (k0 + j) * nthr);
+        }
+#pragma unroll
+        for (u32 j = 0; j < NTT_BATCH; j++) dst[g0 + (k0 + j) * gs] = scaled ? gl_mul(v[j], tw[j]) : v[j];
+      }
+      return;
+    }
     for (u32 i0 = tid; i0 < n; i0 += nthr * NTT_BATCH) {
       u64 v[NTT_BATCH], tw[NTT_BATCH];
 #pragma unroll
@@ -291,7 +355,6 @@ struct NttPass {
       for (u32 j = 0; j < NTT_BATCH; j++) {
         u32 i = i0 + j * nthr;
         if (i >= n) continue;
-        const bool scaled = INV ? p.scale_mode != 0 : p.g_lo != 0;
         dst[global_index(wg, i)] = scaled ? gl_mul(v[j], tw[j]) : v[j];
       }
     }

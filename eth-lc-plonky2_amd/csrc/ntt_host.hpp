@@ -39,10 +39,6 @@ struct NttHost {
       if (inv) w = gl_inv(w);
       return make_pow_table(w, 1, (size_t)1 << B);
     });
-    u64 w16 = gl_root_of_unity(4);
-    if (inv) w16 = gl_inv(w16);
-    u64 cur = 1;
-    for (int k = 0; k < 8; k++) { p.wr[k] = cur; cur = gl_mul(cur, w16); }
     p.nsteps = ntt_step_plan(p.B, p.S, p.step_plan);
   }
   // inter-group twiddles w_{2^(g_lo + B)}^(l * bitrev(t')) of a strided pass as ONE table indexed [t'][l]: a single coalesced

@@ -55,6 +55,24 @@ void emu_poseidon_permute(u64 *s) {
   pos_permute(s, g_rc);
 }
 u64 emu_gl_mul(u64 a, u64 b) { return gl_mul(gl_canon(a), gl_canon(b)); }
+// x * 2^s for the shifts the NTT's register butterflies use (csrc/gl64.hpp gl_shl); x canonical
+u64 emu_gl_shl(u64 x, unsigned s) {
+  switch (s) {
+    case 12: return gl_shl<12>(x);
+    case 24: return gl_shl<24>(x);
+    case 32: return gl_shl<32>(x);
+    case 33: return gl_shl<33>(x);
+    case 36: return gl_shl<36>(x);
+    case 48: return gl_shl<48>(x);
+    case 60: return gl_shl<60>(x);
+    case 63: return gl_shl<63>(x);
+    case 65: return gl_shl<65>(x);
+    case 72: return gl_shl<72>(x);
+    case 84: return gl_shl<84>(x);
+    case 95: return gl_shl<95>(x);
+    default: return ~0ull;
+  }
+}
 void emu_ntt_forward(const u64 *in, u64 *out, u32 lg, u32 ncols, u64 shift, u32 zbits) {
   EmuBackend be; NttHost<EmuBackend> h(be);
   h.forward(in, (u64)1 << lg, out, (u64)1 << (lg + zbits), lg, ncols, shift, zbits);

@@ -17,6 +17,21 @@ def test_emu_field_mul(oracle, emu):
             assert emu.emu_gl_mul(a, b) == (a % P) * (b % P) % P
 
 
+def test_emu_shift_reduce(emu):
+    """gl_shl: multiplication by 2^s as shifts and one canonical subtraction (the 16th roots of unity are +-2^s); the carry cases
+    of the three-word forms: y0 + y1 and y1 + y2 overflowing 32 bits, borrow in the final subtraction, x = p - 1"""
+    rng = np.random.default_rng(5)
+    edge = [0, 1, P - 1, P - 2, 2 ** 32 - 1, 2 ** 32, 0xFFFFFFFF00000000, 0xBFFFFFFFC0000000, 0xBFFFFFFFFFFFFFFF, 0x7FFFFFFFFFFFFFFF,
+            0xFFFFFFFE00000000, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFF, 0x8000000000000000, 0xFFFF0000FFFF0000, 0x0000FFFF0000FFFF]
+    vals = edge + [int(x) % P for x in rng.integers(0, 2 ** 64, size=2000, dtype=np.uint64)]
+    for s in (12, 24, 32, 33, 36, 48, 60, 63, 65, 72, 84, 95):
+        m = pow(2, s, P)
+        for x in vals:
+            assert emu.emu_gl_shl(x, s) == x * m % P, (hex(x), s)
+    # plonky2 POWER_OF_TWO_GENERATOR^(2^28) = w_16 = 2^156 = -2^60: the shift table in csrc/ntt.hpp
+    assert pow(1753635133440165772, 2 ** 28, P) == pow(2, 156, P) == P - 2 ** 60
+
+
 def test_emu_poseidon(oracle, emu):
     rng = np.random.default_rng(1)
     for k in range(64):
