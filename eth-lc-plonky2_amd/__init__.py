@@ -6,7 +6,7 @@ directory name follows the project ("eth-lc-plonky2_amd"); import it as
 `eth_lc_plonky2_amd` (shim module at the repository root).
 """
 from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Params, load_library, standard_params,  # noqa: F401
-                      MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P, proof_to_bytes, proof_from_bytes)
+                      MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P, proof_to_bytes, proof_from_bytes, proof_layout)
 from .build import build_native  # noqa: F401
 from . import binding  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402

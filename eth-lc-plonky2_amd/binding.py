@@ -45,6 +45,15 @@ class CircuitDesc(ctypes.Structure):
                 ("num_regs", ctypes.c_uint32)]
 
 
+class ProofLayout(ctypes.Structure):
+    """lcp2_proof_layout: word offsets of every field of the flat proof"""
+    _fields_ = ([(n, ctypes.c_uint64) for n in ("cap_words", "wires_cap", "zs_cap", "quot_cap", "op_constants", "op_sigmas", "op_wires", "op_zs",
+                                                "op_zs_next", "op_partial_products", "op_quotient", "fri_caps", "queries", "query_words")]
+                + [("q_init_off", ctypes.c_uint64 * 4), ("q_init_cols", ctypes.c_uint64 * 4), ("q_init_sib", ctypes.c_uint64),
+                   ("q_step_off", ctypes.c_uint64 * 8), ("q_step_sib", ctypes.c_uint64 * 8)]
+                + [(n, ctypes.c_uint64) for n in ("final_poly", "final_len", "pow_witness", "total")])
+
+
 _lib = None
 
 
@@ -117,6 +126,7 @@ def load_library():
         "lcp2_circuit_destroy": (None, [c.c_void_p]),
         "lcp2_circuit_digest": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_proof_words": (c.c_size_t, [c.POINTER(Params)]),
+        "lcp2_proof_layout_of": (c.c_int, [c.POINTER(Params), c.POINTER(ProofLayout)]),
         "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]),
         "lcp2_commit_wires": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]),
         "lcp2_commit_wires_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
@@ -390,6 +400,15 @@ def hash_no_pad(values):
 
 
 SER_PUBLIC_INPUT_COUNT = 1
+
+
+def proof_layout(params):
+    """where each field of plonky2's Proof / FriProof sits in the flat proof array (lcp2_proof_layout_of)"""
+    lib, out = load_library(), ProofLayout()
+    rc = lib.lcp2_proof_layout_of(ctypes.byref(params), ctypes.byref(out))
+    if rc:
+        raise Lcp2Error(rc, lib.lcp2_status_str(rc).decode())
+    return out
 
 
 def proof_to_bytes(params, proof, public_inputs, flags=SER_PUBLIC_INPUT_COUNT):

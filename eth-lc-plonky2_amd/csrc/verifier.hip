@@ -276,6 +276,20 @@ inline void put64(uint8_t *o, u64 v) { for (int i = 0; i < 8; i++) o[i] = (uint8
 inline u64 get64(const uint8_t *o) { u64 v = 0; for (int i = 0; i < 8; i++) v |= (u64)o[i] << (8 * i); return v; }
 }  // namespace
 
+extern "C" int lcp2_proof_layout_of(const lcp2_params *p, lcp2_proof_layout *o) {
+  if (!params_ok(p) || !o) return LCP2_E_INVALID;
+  const ProofLayout L(*p);
+  memset(o, 0, sizeof *o);
+  o->cap_words = L.capw; o->wires_cap = L.wires_cap; o->zs_cap = L.zs_cap; o->quot_cap = L.quot_cap;
+  o->op_constants = L.op_constants; o->op_sigmas = L.op_sigmas; o->op_wires = L.op_wires; o->op_zs = L.op_zs; o->op_zs_next = L.op_zs_next;
+  o->op_partial_products = L.op_pp; o->op_quotient = L.op_quot;
+  o->fri_caps = L.fri_caps; o->queries = L.queries; o->query_words = L.query_words; o->q_init_sib = L.q_init_sib;
+  for (int i = 0; i < 4; i++) { o->q_init_off[i] = L.q_init_off[i]; o->q_init_cols[i] = L.q_init_cols[i]; }
+  for (int l = 0; l < LCP2_MAX_FRI_LAYERS; l++) { o->q_step_off[l] = L.q_step_off[l]; o->q_step_sib[l] = L.q_step_sib[l]; }
+  o->final_poly = L.final_poly; o->final_len = L.final_len; o->pow_witness = L.pow_witness; o->total = L.total;
+  return LCP2_OK;
+}
+
 extern "C" size_t lcp2_proof_bytes(const lcp2_params *p, size_t npi, uint32_t flags) {
   if (!params_ok(p)) return 0;
   size_t n = 0;

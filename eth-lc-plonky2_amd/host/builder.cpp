@@ -80,7 +80,7 @@ Target CircuitBuilder::constant(F v) {
   return Target{var};
 }
 
-static Target arithmetic(CircuitBuilder::Impl *b, F c0, Target x, Target y, F c1, Target z) {
+static Target arith_op(CircuitBuilder::Impl *b, F c0, Target x, Target y, F c1, Target z) {
   auto key = std::make_pair(c0, c1);
   auto it = b->arith_open.find(key);
   if (it == b->arith_open.end() || it->second.second == ARITH_OPS) {
@@ -95,24 +95,25 @@ static Target arithmetic(CircuitBuilder::Impl *b, F c0, Target x, Target y, F c1
   b->d->ops.push_back(op);
   return Target{out};
 }
-Target CircuitBuilder::mul_add(Target a, Target b, Target c) { return arithmetic(impl_.get(), 1, a, b, 1, c); }
-Target CircuitBuilder::mul(Target a, Target b) { return arithmetic(impl_.get(), 1, a, b, 0, zero()); }
-Target CircuitBuilder::add(Target a, Target b) { return arithmetic(impl_.get(), 1, a, one(), 1, b); }
-Target CircuitBuilder::sub(Target a, Target b) { return arithmetic(impl_.get(), 1, a, one(), GOLDILOCKS_P - 1, b); }
+Target CircuitBuilder::arithmetic(F c0, Target x, Target y, F c1, Target z) { return arith_op(impl_.get(), c0 % GOLDILOCKS_P, x, y, c1 % GOLDILOCKS_P, z); }
+Target CircuitBuilder::mul_add(Target a, Target b, Target c) { return arith_op(impl_.get(), 1, a, b, 1, c); }
+Target CircuitBuilder::mul(Target a, Target b) { return arith_op(impl_.get(), 1, a, b, 0, zero()); }
+Target CircuitBuilder::add(Target a, Target b) { return arith_op(impl_.get(), 1, a, one(), 1, b); }
+Target CircuitBuilder::sub(Target a, Target b) { return arith_op(impl_.get(), 1, a, one(), GOLDILOCKS_P - 1, b); }
 Target CircuitBuilder::add_many(const std::vector<Target> &terms) {
   if (terms.empty()) return zero();
   Target acc = terms[0];
   for (size_t i = 1; i < terms.size(); i++) acc = add(acc, terms[i]);
   return acc;
 }
-BoolTarget CircuitBuilder::not_(BoolTarget b) { return BoolTarget{arithmetic(impl_.get(), GOLDILOCKS_P - 1, b.target, one(), 1, one())}; }
+BoolTarget CircuitBuilder::not_(BoolTarget b) { return BoolTarget{arith_op(impl_.get(), GOLDILOCKS_P - 1, b.target, one(), 1, one())}; }
 Target CircuitBuilder::select(BoolTarget b, Target x, Target y) { return mul_add(b.target, sub(x, y), y); }
 void CircuitBuilder::assert_bool(BoolTarget b) { connect(mul(b.target, b.target), b.target); }
 Target CircuitBuilder::le_sum(const std::vector<BoolTarget> &bits, size_t first, size_t count) {
   if (first >= bits.size()) return zero();
   const size_t end = count == (size_t)-1 || first + count > bits.size() ? bits.size() : first + count;
   Target acc = bits[end - 1].target;
-  for (size_t i = end - 1; i-- > first;) acc = arithmetic(impl_.get(), 2, acc, one(), 1, bits[i].target);  // 2 acc + bit
+  for (size_t i = end - 1; i-- > first;) acc = arith_op(impl_.get(), 2, acc, one(), 1, bits[i].target);  // 2 acc + bit
   return acc;
 }
 std::vector<BoolTarget> CircuitBuilder::split_le(Target x, size_t nbits) {
@@ -124,6 +125,53 @@ std::vector<BoolTarget> CircuitBuilder::split_le(Target x, size_t nbits) {
   for (auto &b : bits) assert_bool(b);
   connect(le_sum(bits), x);
   return bits;
+}
+
+Target CircuitBuilder::inverse(Target x) {
+  Op op; op.kind = Op::INV; op.x = x.id; op.out = impl_->new_var();
+  impl_->d->ops.push_back(op);
+  Target inv{op.out};
+  connect(mul(x, inv), one());
+  return inv;
+}
+BoolTarget CircuitBuilder::is_equal(Target a, Target b) {
+  // d = a - b, e = 1 - d * (1 / d or 0): e is 1 exactly when d = 0 once d * e = 0 holds
+  Target d = sub(a, b);
+  Op op; op.kind = Op::INV; op.x = d.id; op.out = impl_->new_var();
+  impl_->d->ops.push_back(op);
+  Target e = arithmetic(GOLDILOCKS_P - 1, d, Target{op.out}, 1, one());
+  connect(mul(d, e), zero());
+  return BoolTarget{e};
+}
+std::array<Target, 2> CircuitBuilder::hint_ext_inverse(Target x0, Target x1) {
+  Op op; op.kind = Op::EXT_INV; op.x = x0.id; op.y = x1.id;
+  std::array<Target, 2> out{add_virtual_target(), add_virtual_target()};
+  op.internal = {out[0].id, out[1].id};
+  impl_->d->ops.push_back(op);
+  return out;
+}
+std::array<Target, 2> CircuitBuilder::hint_split_32(Target x) {
+  Op op; op.kind = Op::SPLIT32; op.x = x.id;
+  std::array<Target, 2> out{add_virtual_target(), add_virtual_target()};
+  op.internal = {out[0].id, out[1].id};
+  impl_->d->ops.push_back(op);
+  return out;
+}
+std::array<Target, 12> CircuitBuilder::poseidon(const std::array<Target, 12> &inputs, BoolTarget swap) {
+  Impl *b = impl_.get();
+  const uint32_t row = b->new_row(G_POSEIDON);
+  Op op; op.kind = Op::POSEIDON; op.first_row = row; op.x = swap.target.id;
+  std::array<Target, 12> out;
+  for (uint32_t i = 0; i < 12; i++) {
+    op.in[i] = inputs[i].id;
+    out[i] = Target{b->new_var()};
+    op.internal.push_back(out[i].id);
+    b->bind(row, POS_WIRE_INPUT + i, op.in[i]);
+    b->bind(row, POS_WIRE_OUTPUT + i, out[i].id);
+  }
+  b->bind(row, POS_WIRE_SWAP, swap.target.id);
+  b->d->ops.push_back(op);
+  return out;
 }
 
 void CircuitBuilder::connect(Target a, Target b) {
@@ -214,25 +262,15 @@ std::unique_ptr<CircuitData> CircuitBuilder::build() {
     // circuit_builder.rs::build: public_inputs_hash = hash_n_to_hash_no_pad::<PoseidonHash>(public_inputs) in-circuit (an
     // overwrite-mode sponge of rate 8 over PoseidonGate rows, starting from the zero state, swap = false), connected to
     // the wires of the PublicInputGate, which the gate compares with the hash the transcript uses
-    const uint32_t zero_var = zero().id;
-    std::array<uint32_t, 12> state;
-    state.fill(zero_var);
+    const Target zero_t = zero();
+    std::array<Target, 12> state;
+    state.fill(zero_t);
     const size_t npi_ = d->public_inputs.size();
     for (size_t off = 0; off < npi_; off += 8) {
-      const uint32_t row = b->new_row(G_POSEIDON);
-      Op op; op.kind = Op::POSEIDON; op.first_row = row;
-      for (uint32_t i = 0; i < 12; i++) {
-        op.in[i] = (i < 8 && off + i < npi_) ? d->public_inputs[off + i] : state[i];
-        const uint32_t out = b->new_var();
-        op.internal.push_back(out);
-        b->bind(row, POS_WIRE_INPUT + i, op.in[i]);
-        b->bind(row, POS_WIRE_OUTPUT + i, out);
-      }
-      b->bind(row, POS_WIRE_SWAP, zero_var);
-      for (uint32_t i = 0; i < 12; i++) state[i] = op.internal[i];
-      d->ops.push_back(op);
+      for (uint32_t i = 0; i < 8 && off + i < npi_; i++) state[i] = Target{d->public_inputs[off + i]};
+      state = poseidon(state);
     }
-    for (uint32_t i = 0; i < 4; i++) b->bind(0, i, state[i]);
+    for (uint32_t i = 0; i < 4; i++) b->bind(0, i, state[i].id);
   }
   uint32_t degree_bits = 5;  // room for the cap-height-4 Merkle trees of every FRI layer
   while ((1u << degree_bits) < d->nrows) degree_bits++;
@@ -400,7 +438,9 @@ void eval_sha(const Op &op, Values &V, std::vector<uint64_t> &wires, uint64_t n)
 static void eval_poseidon(const Op &op, Values &V, std::vector<lcp2_cell> &raw) {
   F in[12], row[POS_GATE_WIRES];
   for (int i = 0; i < 12; i++) in[i] = V.get(op.in[i], "poseidon input");
-  poseidon_gate_row(in, false, row);
+  const F swap = V.get(op.x, "poseidon swap flag");
+  if (swap > 1) throw UnsatisfiedError("poseidon swap flag is not boolean");
+  poseidon_gate_row(in, swap == 1, row);
   for (int i = 0; i < 12; i++) V.set(op.internal[i], row[POS_WIRE_OUTPUT + i], "poseidon output");
   for (uint32_t c = POS_WIRE_DELTA; c < POS_GATE_WIRES; c++) raw.push_back(lcp2_cell{op.first_row, c, row[c]});
 }
@@ -413,6 +453,45 @@ static void eval_bits(const Op &op, Values &V) {
   for (unsigned i = 0; i < nbits; i++) V.set(op.internal[i], (x >> i) & 1, "split_le bit");
 }
 
+static inline F f_inv(F x) { return f_pow(x, GOLDILOCKS_P - 2); }
+
+// every generator that runs on the host (everything but SHA): is it ready, and run it
+static bool host_op_ready(const Op &op, const Values &V) {
+  auto has = [&](uint32_t v) { return V.has[V.d->find(v)] != 0; };
+  switch (op.kind) {
+    case Op::ARITH: return has(op.x) && has(op.y) && has(op.z);
+    case Op::BITS: case Op::INV: case Op::SPLIT32: return has(op.x);
+    case Op::EXT_INV: return has(op.x) && has(op.y);
+    case Op::POSEIDON: { if (!has(op.x)) return false; for (int i = 0; i < 12; i++) if (!has(op.in[i])) return false; return true; }
+    case Op::SHA: { for (uint32_t v : op.in) if (!has(v)) return false; return true; }
+    default: return true;
+  }
+}
+static void host_op_eval(const Op &op, Values &V, std::vector<lcp2_cell> &raw) {
+  switch (op.kind) {
+    case Op::CONST: V.set(op.out, op.c0, "constant"); break;
+    case Op::ARITH: {
+      F x = V.get(op.x, "arithmetic input"), y = V.get(op.y, "arithmetic input"), z = V.get(op.z, "arithmetic input");
+      V.set(op.out, f_add(f_mul(f_mul(x, y), op.c0), f_mul(z, op.c1)), "arithmetic output");
+      break;
+    }
+    case Op::BITS: eval_bits(op, V); break;
+    case Op::POSEIDON: eval_poseidon(op, V, raw); break;
+    case Op::INV: { F x = V.get(op.x, "inverse input"); V.set(op.out, x ? f_inv(x) : 0, "inverse"); break; }
+    case Op::EXT_INV: {  // 1 / (a + b X) = (a - b X) / (a^2 - 7 b^2)
+      F a = V.get(op.x, "extension inverse input"), bb = V.get(op.y, "extension inverse input");
+      F norm = f_add(f_mul(a, a), GOLDILOCKS_P - f_mul(7, f_mul(bb, bb)));
+      if (norm >= GOLDILOCKS_P) norm -= GOLDILOCKS_P;
+      F ni = norm ? f_inv(norm) : 0;
+      V.set(op.internal[0], f_mul(a, ni), "extension inverse");
+      V.set(op.internal[1], f_mul(bb ? GOLDILOCKS_P - bb : 0, ni), "extension inverse");
+      break;
+    }
+    case Op::SPLIT32: { F x = V.get(op.x, "split input"); V.set(op.internal[0], x & 0xFFFFFFFFull, "low half"); V.set(op.internal[1], x >> 32, "high half"); break; }
+    case Op::SHA: break;  // the caller's
+  }
+}
+
 void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_t> &wires, std::vector<F> &public_inputs) const {
   const Impl *d = impl_.get();
   const uint64_t n = 1ull << desc_.params.degree_bits;
@@ -421,14 +500,6 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
   for (auto &e : pw.entries()) V.set(e.first, e.second, "PartialWitness");
   // plonky2 runs its generators from a worklist; here the steps are re-scanned until none is left waiting
   // (gadgets may be wired after they are built: ssz_sync_committee connects the leaves of an existing tree)
-  auto ready = [&](const Op &op) {
-    auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
-    if (op.kind == Op::ARITH) return has(op.x) && has(op.y) && has(op.z);
-    if (op.kind == Op::BITS) return has(op.x);
-    if (op.kind == Op::SHA) { for (uint32_t v : op.in) if (!has(v)) return false; }
-    if (op.kind == Op::POSEIDON) { for (int i = 0; i < 12; i++) if (!has(op.in[i])) return false; }
-    return true;
-  };
   std::vector<lcp2_cell> raw;
   std::vector<const Op *> pending;
   for (const Op &op : d->ops) pending.push_back(&op);
@@ -436,18 +507,9 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
     std::vector<const Op *> waiting;
     for (const Op *opp : pending) {
       const Op &op = *opp;
-      if (!ready(op)) { waiting.push_back(opp); continue; }
-      switch (op.kind) {
-        case Op::CONST: V.set(op.out, op.c0, "constant"); break;
-        case Op::ARITH: {
-          F x = V.get(op.x, "arithmetic input"), y = V.get(op.y, "arithmetic input"), z = V.get(op.z, "arithmetic input");
-          V.set(op.out, f_add(f_mul(f_mul(x, y), op.c0), f_mul(z, op.c1)), "arithmetic output");
-          break;
-        }
-        case Op::SHA: eval_sha(op, V, wires, n); break;
-        case Op::BITS: eval_bits(op, V); break;
-        case Op::POSEIDON: eval_poseidon(op, V, raw); break;
-      }
+      if (!host_op_ready(op, V)) { waiting.push_back(opp); continue; }
+      if (op.kind == Op::SHA) eval_sha(op, V, wires, n);
+      else host_op_eval(op, V, raw);
     }
     if (waiting.size() == pending.size()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
     pending.swap(waiting);
@@ -465,6 +527,12 @@ CircuitData::~CircuitData() {
     if (impl_->gpu) lcp2_circuit_destroy(impl_->gpu);
     if (impl_->verifier) lcp2_circuit_destroy(impl_->verifier);
   }
+}
+
+void CircuitData::verifier_only_data(uint64_t digest[4], std::vector<uint64_t> &cap) const {
+  if (!impl_->gpu) throw std::runtime_error("verifier_only_data needs attach_gpu()");
+  cap.assign((size_t)4 << desc_.params.cap_height, 0);
+  if (lcp2_circuit_digest(impl_->gpu, digest, cap.data()) != LCP2_OK) throw std::runtime_error("lcp2_circuit_digest failed");
 }
 
 void CircuitData::attach_gpu(lcp2_ctx *ctx) {
@@ -489,7 +557,6 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   for (auto &e : pw.entries()) V.set(e.first, e.second, "PartialWitness");
   std::vector<const Op *> host_ops, sha_ops;
   for (const Op &op : d->ops) (op.kind == Op::SHA ? sha_ops : host_ops).push_back(&op);
-  auto has = [&](uint32_t v) { return V.has[d->find(v)] != 0; };
   std::vector<lcp2_cell> cells;  // everything the host writes: unbound cells of PoseidonGate rows, then the bound cells
   while (true) {
     bool progress = true;
@@ -497,17 +564,8 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       progress = false;
       std::vector<const Op *> waiting;
       for (const Op *op : host_ops) {
-        if (op->kind == Op::ARITH && !(has(op->x) && has(op->y) && has(op->z))) { waiting.push_back(op); continue; }
-        if (op->kind == Op::BITS && !has(op->x)) { waiting.push_back(op); continue; }
-        if (op->kind == Op::POSEIDON) {
-          bool ok = true;
-          for (int i = 0; i < 12; i++) ok = ok && has(op->in[i]);
-          if (!ok) { waiting.push_back(op); continue; }
-          eval_poseidon(*op, V, cells);
-        }
-        else if (op->kind == Op::CONST) V.set(op->out, op->c0, "constant");
-        else if (op->kind == Op::BITS) eval_bits(*op, V);
-        else V.set(op->out, f_add(f_mul(f_mul(V.get(op->x, "x"), V.get(op->y, "y")), op->c0), f_mul(V.get(op->z, "z"), op->c1)), "arithmetic output");
+        if (!host_op_ready(*op, V)) { waiting.push_back(op); continue; }
+        host_op_eval(*op, V, cells);
         progress = true;
       }
       host_ops.swap(waiting);

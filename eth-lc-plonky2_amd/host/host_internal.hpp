@@ -39,8 +39,10 @@ extern const uint32_t SHA_IV[8];
 
 // one generator step, evaluated in creation order by generate_witness
 struct Op {
-  enum Kind { CONST, ARITH, SHA, BITS, POSEIDON } kind;  // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
-                                                         // POSEIDON: in[0..12) -> internal[0..12) on row first_row (swap = 0)
+  enum Kind { CONST, ARITH, SHA, BITS, POSEIDON, INV, EXT_INV, SPLIT32 } kind;
+  // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
+  // POSEIDON: in[0..12), swap flag x -> internal[0..12) on row first_row
+  // INV: x -> out = 1 / x (0 for 0) ; EXT_INV: (x, y) -> internal[0..2) ; SPLIT32: x -> internal = {low 32 bits, high 32 bits}
   uint32_t out = 0, x = 0, y = 0, z = 0;  // CONST: out ; ARITH: x, y, z -> out
   F c0 = 0, c1 = 0;                        // CONST: c0 = value
   // SHA: message words in[16] -> digest out8[8]; internal words by row

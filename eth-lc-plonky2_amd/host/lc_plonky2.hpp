@@ -88,6 +88,21 @@ class CircuitBuilder {
   Target add(Target a, Target b);
   Target sub(Target a, Target b);
   Target add_many(const std::vector<Target> &terms);
+  Target arithmetic(F const_0, Target x, Target y, F const_1, Target z);  // const_0 * x * y + const_1 * z: one ArithmeticGate operation
+  Target mul_const(F c, Target x) { return arithmetic(c, x, one(), 0, zero()); }
+  Target add_const(Target x, F c) { return arithmetic(1, x, one(), c, one()); }
+  Target inverse(Target x);                              // 1 / x; x = 0 cannot be proved (x * inv = 1)
+  BoolTarget is_equal(Target a, Target b);               // builder.is_equal
+  BoolTarget and_(BoolTarget a, BoolTarget b) { return BoolTarget{mul(a.target, b.target)}; }
+  BoolTarget or_(BoolTarget a, BoolTarget b) { return BoolTarget{arithmetic(GOLDILOCKS_P - 1, a.target, b.target, 1, add(a.target, b.target))}; }
+  // one PoseidonGate row: the permutation of `inputs`, with inputs[0..4) and [4..8) exchanged first when swap is set
+  // (plonky2 gates/poseidon.rs; what hash_n_to_hash_no_pad, the Merkle-path and the Challenger gadgets are made of)
+  std::array<Target, 12> poseidon(const std::array<Target, 12> &inputs, BoolTarget swap);
+  std::array<Target, 12> poseidon(const std::array<Target, 12> &inputs) { return poseidon(inputs, BoolTarget{zero()}); }
+  // generators without constraints (the caller constrains the results): the inverse of x0 + x1 X in F[X]/(X^2 - 7) (0 for 0),
+  // and the canonical value of x as low / high 32-bit halves
+  std::array<Target, 2> hint_ext_inverse(Target x0, Target x1);
+  std::array<Target, 2> hint_split_32(Target x);
   BoolTarget not_(BoolTarget b);                         // builder.not(b) = 1 - b
   Target select(BoolTarget b, Target x, Target y);       // builder._if / select: b ? x : y
   void assert_bool(BoolTarget b);                        // b * b = b
@@ -138,6 +153,8 @@ class CircuitData {
   void generate_witness(const PartialWitness &pw, std::vector<uint64_t> &wires, std::vector<F> &public_inputs) const;
   // attaches the MI355X backend: lcp2_circuit_create on `ctx` (commits the preprocessed polynomials)
   void attach_gpu(lcp2_ctx *ctx);
+  // VerifierOnlyCircuitData { constants_sigmas_cap, circuit_digest } of the attached circuit (what a recursive verifier is given)
+  void verifier_only_data(uint64_t digest[4], std::vector<uint64_t> &constants_sigmas_cap) const;
   ProofWithPublicInputs prove(const PartialWitness &pw);          // data.prove(pw): needs attach_gpu (no CPU prover here)
   // the device half of generate_partial_witness: SHA-256 rows are computed and written in HBM (K10), the few
   // remaining cells are scattered from the host; leaves the witness in the circuit's device buffer

@@ -258,6 +258,22 @@ int lcp2_circuit_digest(const lcp2_circuit *c, uint64_t digest[4], uint64_t *cap
  * opening_proof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness }). */
 size_t lcp2_proof_words(const lcp2_params *p);
 
+/* Word offsets of every field of the flat proof (what a caller needs to map it onto plonky2's Proof / FriProof structs, and
+ * what the recursive verifier gadget of the host layer walks).  Openings are extension elements (2 words each), caps are
+ * 4 << cap_height words.  Query round q starts at queries + q * query_words; inside it, initial-tree opening o (0 constants
+ * and sigmas, 1 wires, 2 Zs and partial products, 3 quotient chunks) is q_init_cols[o] leaf elements at q_init_off[o] followed
+ * by q_init_sib sibling digests; FRI layer l is 2 << fri_arity_bits[l] words of evaluations at q_step_off[l] followed by
+ * q_step_sib[l] sibling digests. */
+typedef struct {
+  uint64_t cap_words, wires_cap, zs_cap, quot_cap;
+  uint64_t op_constants, op_sigmas, op_wires, op_zs, op_zs_next, op_partial_products, op_quotient;
+  uint64_t fri_caps, queries, query_words;
+  uint64_t q_init_off[4], q_init_cols[4], q_init_sib;
+  uint64_t q_step_off[LCP2_MAX_FRI_LAYERS], q_step_sib[LCP2_MAX_FRI_LAYERS];
+  uint64_t final_poly, final_len, pow_witness, total;
+} lcp2_proof_layout;
+int lcp2_proof_layout_of(const lcp2_params *p, lcp2_proof_layout *out);
+
 /* data.prove(pw): wires is the full witness (generate_partial_witness output), column-major
  * [num_wires][n]; public_inputs (num_public_inputs elements, must equal the circuit's count) and proof
  * (proof_words words, must equal lcp2_proof_words) are host buffers.  The proof-of-work witness is the

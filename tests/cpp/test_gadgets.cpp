@@ -18,6 +18,7 @@
 #include <functional>
 #include <string>
 #include "../../eth-lc-plonky2_amd/host/gadgets.hpp"
+#include "../../eth-lc-plonky2_amd/host/recursion.hpp"
 #include "../../oracle/plonk.h"
 #include "golden_data.hpp"
 
@@ -369,6 +370,102 @@ static void test_update_validity_equal_slots_and_343() { update_validity(7, 7, F
 static void test_update_validity_finalized_before_current_panics() { update_validity(LC634__FINALIZED_SLOT, LC633__FINALIZED_SLOT, 428); }
 static void test_update_validity_threshold_not_exceeded_panics() { update_validity(1, 2, FINALITY_THRESHOLD); }
 
+// ---- the recursive verifier (src/targets.rs:468-482, src/main.rs:172-176: add_virtual_proof_with_pis + verify_proof of an inner
+// proof whose public inputs are connected into the outer circuit; the reference's inner proof is the BLS-signature verifier,
+// which does not exist here: the inner circuit below is a stand-in with the same interface - a proof with public inputs)
+struct InnerProof {
+  std::unique_ptr<CircuitData> data;
+  ProofWithPublicInputs proof;
+  uint64_t digest[4];
+  std::vector<uint64_t> cap;
+};
+// inner circuit: public inputs (x, y, x * y + x, low 16 bits of y recomposed) and, optionally, one two_to_one_sha256
+static InnerProof prove_inner(bool with_sha, F x_val, F y_val) {
+  InnerProof in;
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  Target x = builder.add_virtual_target(), y = builder.add_virtual_target();
+  Target z = builder.mul_add(x, y, x);
+  std::vector<BoolTarget> bits = builder.split_le(y, 20);
+  Target low = builder.le_sum(bits, 0, 16);
+  builder.register_public_input(x); builder.register_public_input(y); builder.register_public_input(z); builder.register_public_input(low);
+  Hash256Target l, r;
+  if (with_sha) {
+    l = builder.add_virtual_hash256_target(); r = builder.add_virtual_hash256_target();
+    Hash256Target d = builder.two_to_one_sha256(l, r);
+    for (int i = 0; i < 8; i++) builder.register_public_input(d[i].t);
+  }
+  in.data = builder.build();
+  PartialWitness pw;
+  pw.set_target(x, x_val); pw.set_target(y, y_val);
+  if (with_sha) { pw.set_hash256_target(l, ZERO_ROOT_2); pw.set_hash256_target(r, ZERO_ROOT_4); }
+  const CircuitDescription &D = in.data->description();
+  if (g_gpu) {
+    in.data->attach_gpu(g_ctx);
+    in.proof = in.data->prove(pw);
+    in.data->verify(in.proof);
+    in.data->verifier_only_data(in.digest, in.cap);
+  } else {  // the oracle is the CPU prover of the tests
+    std::vector<uint64_t> wires;
+    in.data->generate_witness(pw, wires, in.proof.public_inputs);
+    orc_params op;
+    memcpy(&op, &D.params, sizeof op);
+    std::vector<orc_gate> og(D.gates.size());
+    memcpy(og.data(), D.gates.data(), og.size() * sizeof(orc_gate));
+    orc_circuit *oc = orc_circuit_new(&op, D.constants_sigmas.data(), D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(),
+                                      D.imm.data(), D.imm.size(), D.num_public_inputs);
+    if (!oc) throw std::runtime_error("oracle rejected the inner circuit");
+    in.proof.proof.resize(orc_proof_words(&op));
+    orc_prove(oc, wires.data(), in.proof.public_inputs.data(), in.proof.proof.data());
+    if (orc_verify(oc, in.proof.proof.data(), in.proof.public_inputs.data()) != 0) throw std::runtime_error("oracle verifier rejected the inner proof");
+    in.cap.resize((size_t)4 << D.params.cap_height);
+    orc_circuit_digest(oc, in.digest, in.cap.data());
+    orc_circuit_free(oc);
+  }
+  return in;
+}
+// outer circuit: verify_proof(inner) with the inner public inputs re-exported; `tamper`: the word of the inner proof to corrupt
+static void recursive_verifier(bool with_sha, bool constant_vd, long tamper, bool wrong_public_input = false, bool wrong_digest = false) {
+  InnerProof in = prove_inner(with_sha, 123456789, 0xABCDE);
+  const CommonCircuitData common = CommonCircuitData::of(in.data->description());
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  ProofWithPublicInputsTarget pt = add_virtual_proof_with_pis(builder, common);
+  VerifierCircuitTarget vd = constant_vd ? constant_verifier_data(builder, in.digest, in.cap) : add_virtual_verifier_data(builder, common.params.cap_height);
+  verify_proof(builder, pt, vd, common);
+  for (Target t : pt.public_inputs) builder.register_public_input(t);
+  const size_t rows = builder.num_gates();
+  auto data = builder.build();
+  printf("recursive verifier of a 2^%u-row proof (%zu words): %zu gates, 2^%u rows\n", common.params.degree_bits, pt.proof.size(), rows, data->degree_bits());
+  ProofWithPublicInputs p = in.proof;
+  lcp2_proof_layout L;
+  lcp2_proof_layout_of(&common.params, &L);
+  if (tamper >= 0) {
+    const size_t where[] = {L.op_wires + 3, L.quot_cap + 1, L.queries + L.q_init_off[1] + 7, L.queries + L.query_words + L.q_step_off[0] + 2, L.final_poly, L.pow_witness,
+                            L.queries + 2 * L.query_words + L.q_init_off[0] + L.q_init_cols[0] + 5};
+    size_t w = where[tamper];
+    p.proof[w] = p.proof[w] == 5 ? 6 : 5;
+  }
+  if (wrong_public_input) p.public_inputs[2] += 1;
+  PartialWitness pw;
+  set_proof_with_pis_target(pw, pt, p);
+  if (!constant_vd) {
+    uint64_t dg[4] = {in.digest[0], in.digest[1], in.digest[2], in.digest[3]};
+    if (wrong_digest) dg[1] ^= 1;
+    set_verifier_data_target(pw, vd, dg, in.cap);
+  }
+  prove_and_verify(*data, pw);
+}
+static void test_recursive_verifier() { recursive_verifier(false, false, -1); }
+static void test_recursive_verifier_constant_verifier_data_sha_inner() { recursive_verifier(true, true, -1); }
+static void test_recursive_verifier_tampered_opening_panics() { recursive_verifier(false, false, 0); }
+static void test_recursive_verifier_tampered_cap_panics() { recursive_verifier(false, false, 1); }
+static void test_recursive_verifier_tampered_leaf_panics() { recursive_verifier(false, false, 2); }
+static void test_recursive_verifier_tampered_fri_layer_panics() { recursive_verifier(false, false, 3); }
+static void test_recursive_verifier_tampered_final_poly_panics() { recursive_verifier(false, false, 4); }
+static void test_recursive_verifier_tampered_pow_panics() { recursive_verifier(false, false, 5); }
+static void test_recursive_verifier_tampered_sibling_panics() { recursive_verifier(false, false, 6); }
+static void test_recursive_verifier_wrong_public_input_panics() { recursive_verifier(false, false, -1, true); }
+static void test_recursive_verifier_wrong_digest_panics() { recursive_verifier(false, false, -1, false, true); }
+
 struct TestCase { const char *name; std::function<void()> fn; bool should_panic; };
 static const TestCase TESTS[] = {
     {"test_merkle_root_2_leaves", test_merkle_root_2_leaves, false},
@@ -396,6 +493,17 @@ static const TestCase TESTS[] = {
     {"test_update_validity_equal_slots_and_343", test_update_validity_equal_slots_and_343, false},
     {"test_update_validity_finalized_before_current_panics", test_update_validity_finalized_before_current_panics, true},
     {"test_update_validity_threshold_not_exceeded_panics", test_update_validity_threshold_not_exceeded_panics, true},
+    {"test_recursive_verifier", test_recursive_verifier, false},
+    {"test_recursive_verifier_constant_verifier_data_sha_inner", test_recursive_verifier_constant_verifier_data_sha_inner, false},
+    {"test_recursive_verifier_tampered_opening_panics", test_recursive_verifier_tampered_opening_panics, true},
+    {"test_recursive_verifier_tampered_cap_panics", test_recursive_verifier_tampered_cap_panics, true},
+    {"test_recursive_verifier_tampered_leaf_panics", test_recursive_verifier_tampered_leaf_panics, true},
+    {"test_recursive_verifier_tampered_fri_layer_panics", test_recursive_verifier_tampered_fri_layer_panics, true},
+    {"test_recursive_verifier_tampered_final_poly_panics", test_recursive_verifier_tampered_final_poly_panics, true},
+    {"test_recursive_verifier_tampered_pow_panics", test_recursive_verifier_tampered_pow_panics, true},
+    {"test_recursive_verifier_tampered_sibling_panics", test_recursive_verifier_tampered_sibling_panics, true},
+    {"test_recursive_verifier_wrong_public_input_panics", test_recursive_verifier_wrong_public_input_panics, true},
+    {"test_recursive_verifier_wrong_digest_panics", test_recursive_verifier_wrong_digest_panics, true},
 };
 
 int main(int argc, char **argv) {

@@ -15,6 +15,14 @@ CPU_TESTS = [
     "test_find_sync_committee_stale_period_panics", "test_find_sync_committee_previous_period_panics",
     "test_slot_connect_rejects_wide_encoding_panics", "test_update_validity", "test_update_validity_equal_slots_and_343",
     "test_update_validity_finalized_before_current_panics", "test_update_validity_threshold_not_exceeded_panics",
+    # the recursive verifier gadget (host/recursion.cpp): an inner proof checked natively and in-circuit; each tampered word
+    # (opening, cap, leaf, FRI evaluation, final polynomial, PoW witness, Merkle sibling, public input, digest) must fail
+    "test_recursive_verifier", "test_recursive_verifier_constant_verifier_data_sha_inner",
+    "test_recursive_verifier_tampered_opening_panics", "test_recursive_verifier_tampered_cap_panics",
+    "test_recursive_verifier_tampered_leaf_panics", "test_recursive_verifier_tampered_fri_layer_panics",
+    "test_recursive_verifier_tampered_final_poly_panics", "test_recursive_verifier_tampered_pow_panics",
+    "test_recursive_verifier_tampered_sibling_panics", "test_recursive_verifier_wrong_public_input_panics",
+    "test_recursive_verifier_wrong_digest_panics",
 ]
 
 
