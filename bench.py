@@ -78,11 +78,12 @@ def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
         return None
 
 
-def real_lc_step(extra_committees=0):
+def real_lc_step(extra_committees=0, recursive=False):
     """Not the headline number: the reference's own update pair 633 -> 634 through examples/lc_prover (the C++ host layer's
-    light-client circuit in its own SHA-256 layout, BLS verifier stubbed), if the binary has been built.  The proof time includes
-    the device-side witness generation (K10).  extra_committees = 6 adds six more SyncCommitteeSSZ gadgets: 7 207 two_to_one_sha256,
-    2.24 M gates, 2^22 rows - the reference's scale (README.md:71) made of real gadgets."""
+    light-client circuit in its own SHA-256 layout), if the binary has been built.  The proof time includes the device-side witness
+    generation (K10).  extra_committees = 6 adds six more SyncCommitteeSSZ gadgets: 7 207 two_to_one_sha256, 2.24 M gates, 2^22 rows -
+    the reference's scale (README.md:71) made of real gadgets.  recursive: the circuit also verifies, as the reference's does, a proof
+    with the BLS proof's 25 216 public inputs (of the stand-in statement circuit: the BLS12-381 verifier itself is out of scope)."""
     import re
     import subprocess
     import tempfile
@@ -98,8 +99,8 @@ def real_lc_step(extra_committees=0):
                 paths.append(os.path.join(d, "u%s.json" % tag))
                 json.dump(lc[tag], open(paths[-1], "w"))
             env = dict(os.environ, LCP2_PROF="1")
-            r = subprocess.run([exe] + paths + ["--repeat", "3", "--extra-committees", str(extra_committees)], capture_output=True, text=True,
-                               timeout=600, env=env)
+            r = subprocess.run([exe] + paths + ["--repeat", "3", "--extra-committees", str(extra_committees)] + (["--bls-proof-stand-in"] if recursive else []),
+                               capture_output=True, text=True, timeout=600, env=env)
         ms = [float(x) for x in re.findall(r"proved in ([0-9.]+) ms", r.stdout)]
         bits = re.search(r"degree_bits (\d+)", r.stdout)
         gates = re.search(r"(\d+) gates", r.stdout)
@@ -107,6 +108,10 @@ def real_lc_step(extra_committees=0):
         if r.returncode != 0 or len(ms) < 3 or not bits:
             return None
         what = "light-client step for updates 633 -> 634 (examples/lc_prover)"
+        inner = re.search(r"inner proof .*: 2\^(\d+) rows, (\d+) public inputs, build ([0-9.]+) ms, inner prove ([0-9.]+) ms", r.stdout)
+        if recursive and inner:
+            what += (" with the recursive verification of a 2^%s-row inner proof that has the BLS proof's %s public inputs (stand-in statement circuit; "
+                     "inner proof %s ms, not in ms_per_proof)" % (inner.group(1), inner.group(2), inner.group(4)))
         if extra_committees:
             what += " + %d more SyncCommitteeSSZ gadgets: %s gates" % (extra_committees, gates.group(1) if gates else "?")
         return {"workload": what + ", device witness generation included, proof verified", "degree_bits": int(bits.group(1)),
@@ -315,6 +320,9 @@ def main():
             step_633 = real_lc_step()
             if step_633:
                 out["config"]["real_lc_step"] = step_633
+            rec = real_lc_step(recursive=True)
+            if rec:
+                out["config"]["real_lc_step_recursive"] = rec
             big = real_lc_step(extra_committees=6)
             if big:
                 out["config"]["real_gadget_circuit_2p22"] = big

@@ -272,7 +272,7 @@ UpdateValidityTarget add_virtual_update_validity_target(CircuitBuilder &builder)
   return t;
 }
 
-ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
+ProofTarget add_virtual_proof_target(CircuitBuilder &builder, const CommonCircuitData *bls_sig_cd) {
   ProofTarget p;
   p.signing_root_bytes = builder.add_virtual_target_arr<32>();
   Hash256Target signing_root = builder.add_virtual_hash256_target();
@@ -317,10 +317,23 @@ ProofTarget add_virtual_proof_target(CircuitBuilder &builder) {
   UpdateValidityTarget update_validity_target = add_virtual_update_validity_target(builder);
   SlotConnectTarget finalized_slot_connect = add_virtual_biguint_hash256_connect_target(builder);
 
-  // *** signing root ***   (the recursive BLS verifier that consumes signing_root_bytes / signature_bytes is stubbed)
+  // *** signing root ***
   builder.connect_hash256(signing_root_target.signing_root, signing_root);
   builder.connect_hash256(signing_root_target.header_root, p.attested_header_root);
   builder.connect_hash256(signing_root_target.domain, p.domain);
+  if (bls_sig_cd) {  // src/targets.rs:468-482
+    if (bls_sig_cd->num_public_inputs != BLS_PROOF_PUBLIC_INPUTS) throw std::runtime_error("add_virtual_proof_target: the BLS proof must have 25 216 public inputs");
+    p.has_bls_proof = true;
+    p.bls_proof = add_virtual_proof_with_pis(builder, *bls_sig_cd);
+    p.bls_verifier_data = add_virtual_verifier_data(builder, bls_sig_cd->params.cap_height);
+    verify_proof(builder, p.bls_proof, p.bls_verifier_data, *bls_sig_cd);
+    for (size_t idx = 0; idx < 32; idx++) builder.connect(p.bls_proof.public_inputs[idx], p.signing_root_bytes[idx]);
+    for (size_t idx = 0; idx < 96; idx++) builder.connect(p.bls_proof.public_inputs[idx + 32], p.signature_bytes[idx]);
+    for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) {
+      for (size_t j = 0; j < G1_PUBKEY_SIZE; j++) builder.connect(p.bls_proof.public_inputs[32 + 96 + i * (G1_PUBKEY_SIZE + 1) + j], p.sync_committee.pubkeys[i][j]);
+      builder.connect(p.bls_proof.public_inputs[32 + 96 + i * (G1_PUBKEY_SIZE + 1) + G1_PUBKEY_SIZE], p.sync_committee_bits[i].target);
+    }
+  }
   // *** attested block header ***
   builder.connect_hash256(attested.body_root, p.attested_body_root);
   builder.connect_hash256(attested.header_root, p.attested_header_root);
@@ -415,6 +428,32 @@ void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], c
     witness.set_target_arr(target.sync_committee.pubkeys[i], std::vector<F>(sync_committee_pubkeys[i], sync_committee_pubkeys[i] + G1_PUBKEY_SIZE));
   witness.set_target_arr(target.sync_committee.aggregate_pubkey, std::vector<F>(sync_committee_aggregate, sync_committee_aggregate + G1_PUBKEY_SIZE));
   witness.set_target_arr(target.signature_bytes, std::vector<F>(signature, signature + 96));
+}
+
+void set_bls_proof_target(PartialWitness &witness, const ProofTarget &target, const ProofWithPublicInputs &bls_proof, const uint64_t circuit_digest[4],
+                          const std::vector<uint64_t> &constants_sigmas_cap) {
+  if (!target.has_bls_proof) throw std::runtime_error("set_bls_proof_target: the circuit was built without the recursive verifier");
+  set_proof_with_pis_target(witness, target.bls_proof, bls_proof);
+  set_verifier_data_target(witness, target.bls_verifier_data, circuit_digest, constants_sigmas_cap);
+}
+
+BlsStatementStandIn build_bls_statement_stand_in() {
+  BlsStatementStandIn c;
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  for (size_t i = 0; i < BLS_PROOF_PUBLIC_INPUTS; i++) c.public_inputs.push_back(builder.add_virtual_target());
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) builder.assert_bool(BoolTarget{c.public_inputs[32 + 96 + i * (G1_PUBKEY_SIZE + 1) + G1_PUBKEY_SIZE]});
+  builder.register_public_inputs(c.public_inputs);
+  c.data = builder.build();
+  return c;
+}
+void set_bls_statement_stand_in(PartialWitness &witness, const BlsStatementStandIn &c, const uint8_t signing_root[32], const uint8_t signature[96],
+                                const uint8_t pubkeys[][48], const std::vector<bool> &bits) {
+  for (size_t i = 0; i < 32; i++) witness.set_target(c.public_inputs[i], signing_root[i]);
+  for (size_t i = 0; i < 96; i++) witness.set_target(c.public_inputs[32 + i], signature[i]);
+  for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++) {
+    for (size_t j = 0; j < G1_PUBKEY_SIZE; j++) witness.set_target(c.public_inputs[32 + 96 + i * (G1_PUBKEY_SIZE + 1) + j], pubkeys[i][j]);
+    witness.set_target(c.public_inputs[32 + 96 + i * (G1_PUBKEY_SIZE + 1) + G1_PUBKEY_SIZE], bits[i] ? 1 : 0);
+  }
 }
 
 }  // namespace lc

@@ -7,6 +7,7 @@
 //                                  add_virtual_* / set_* functions (the SHA-256-only sub-circuits)
 #pragma once
 #include "lc_plonky2.hpp"
+#include "recursion.hpp"
 
 namespace lc {
 
@@ -53,8 +54,16 @@ struct VerifySyncCommitteeTarget {
   Hash256Target cur_sync_committee_i, cur_sync_committee_ii, new_sync_committee_i, new_sync_committee_ii, finalized_state_root;
   std::vector<Hash256Target> new_sync_committee_ii_branch;
 };
-// src/targets.rs:84-119 ProofTarget without the recursive BLS proof / verifier data and the BigUint slot copies
+// public inputs of the reference's BLS-signature proof, in its order (src/targets.rs:471-482): the 32 signing-root bytes, the 96
+// signature bytes, then per committee member its 48 pubkey bytes and its participation bit
+constexpr size_t BLS_PROOF_PUBLIC_INPUTS = 32 + 96 + SYNC_COMMITTEE_SIZE * (G1_PUBKEY_SIZE + 1);  // 25 216
+
+// src/targets.rs:84-119 ProofTarget (the BigUint slot copies are the u64 form above).  bls_proof / bls_verifier_data are present
+// when add_virtual_proof_target was given the common data of a BLS-signature proof to verify recursively.
 struct ProofTarget {
+  bool has_bls_proof = false;
+  ProofWithPublicInputsTarget bls_proof;
+  VerifierCircuitTarget bls_verifier_data;
   std::array<Target, 32> signing_root_bytes;
   Hash256Target attested_header_root, domain, attested_slot, attested_proposer_index, attested_parent_root, attested_state_root,
       attested_body_root, finalized_header_root;
@@ -96,8 +105,26 @@ SlotConnectTarget add_virtual_biguint_hash256_connect_target(CircuitBuilder &bui
 FindSyncCommitteeTarget add_virtual_find_sync_committee_target(CircuitBuilder &builder);
 // src/targets.rs:304-332: cur_slot <= finalized_slot and participation > FINALITY_THRESHOLD (range checks of the differences)
 UpdateValidityTarget add_virtual_update_validity_target(CircuitBuilder &builder);
-// src/targets.rs:391-683 with only the recursive BLS verifier (:468-482) stubbed: BASELINE configs[2]
-ProofTarget add_virtual_proof_target(CircuitBuilder &builder);
+// src/targets.rs:391-683.  bls_sig_cd = nullptr: the recursive BLS verifier (:468-482) is left out (BASELINE configs[2]).
+// With the common data of an inner proof that has BLS_PROOF_PUBLIC_INPUTS public inputs, :468-482 is built as in the reference:
+// add_virtual_proof_with_pis + add_virtual_verifier_data + verify_proof, and the inner public inputs are connected to the signing
+// root bytes, the signature bytes, the committee's pubkey bytes and the participation bits.
+ProofTarget add_virtual_proof_target(CircuitBuilder &builder, const CommonCircuitData *bls_sig_cd = nullptr);
+// the tail of set_proof_target in the reference (set_proof_with_pis_target + set_verifier_data_target for the BLS proof)
+void set_bls_proof_target(PartialWitness &witness, const ProofTarget &target, const ProofWithPublicInputs &bls_proof, const uint64_t circuit_digest[4],
+                          const std::vector<uint64_t> &constants_sigmas_cap);
+
+// A STAND-IN for the circuit whose proof the reference verifies here (starky_bls12_381's aggregate_proof, src/main.rs:170): it
+// has the same public inputs in the same order and constrains only that the participation flags are boolean - it says NOTHING
+// about the BLS signature.  It exists so that the recursive half of the light-client circuit (proof target, verifier data,
+// verify_proof, the 25 216 connections) can be built, proved and measured; the BLS12-381 verifier itself is out of scope.
+struct BlsStatementStandIn {
+  std::unique_ptr<CircuitData> data;
+  std::vector<Target> public_inputs;  // BLS_PROOF_PUBLIC_INPUTS
+};
+BlsStatementStandIn build_bls_statement_stand_in();
+void set_bls_statement_stand_in(PartialWitness &witness, const BlsStatementStandIn &circuit, const uint8_t signing_root[32], const uint8_t signature[96],
+                                const uint8_t sync_committee_pubkeys[][48], const std::vector<bool> &sync_committee_bits);
 // src/targets.rs:771-898 (same argument order; the BLS proof / verifier data arguments are dropped)
 void set_proof_target(PartialWitness &witness, const uint8_t signing_root[32], const uint8_t domain[32], uint64_t attested_slot,
                       uint64_t attested_proposer_index, const uint8_t attested_header_root[32], const uint8_t attested_parent_root[32],

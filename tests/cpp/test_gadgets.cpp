@@ -116,6 +116,39 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
   orc_circuit_free(oc);
 }
 
+// an inner proof for the recursion tests: data.prove on the GPU in gpu mode, the oracle (the CPU prover of the tests) otherwise
+struct InnerProof {
+  std::unique_ptr<CircuitData> data;
+  ProofWithPublicInputs proof;
+  uint64_t digest[4];
+  std::vector<uint64_t> cap;
+};
+static void prove_standalone(InnerProof &in, const PartialWitness &pw) {
+  const CircuitDescription &D = in.data->description();
+  if (g_gpu) {
+    in.data->attach_gpu(g_ctx);
+    in.proof = in.data->prove(pw);
+    in.data->verify(in.proof);
+    in.data->verifier_only_data(in.digest, in.cap);
+    return;
+  }
+  std::vector<uint64_t> wires;
+  in.data->generate_witness(pw, wires, in.proof.public_inputs);
+  orc_params op;
+  memcpy(&op, &D.params, sizeof op);
+  std::vector<orc_gate> og(D.gates.size());
+  memcpy(og.data(), D.gates.data(), og.size() * sizeof(orc_gate));
+  orc_circuit *oc = orc_circuit_new(&op, D.constants_sigmas.data(), D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(),
+                                    D.imm.data(), D.imm.size(), D.num_public_inputs);
+  if (!oc) throw std::runtime_error("oracle rejected the inner circuit");
+  in.proof.proof.resize(orc_proof_words(&op));
+  orc_prove(oc, wires.data(), in.proof.public_inputs.data(), in.proof.proof.data());
+  if (orc_verify(oc, in.proof.proof.data(), in.proof.public_inputs.data()) != 0) throw std::runtime_error("oracle verifier rejected the inner proof");
+  in.cap.resize((size_t)4 << D.params.cap_height);
+  orc_circuit_digest(oc, in.digest, in.cap.data());
+  orc_circuit_free(oc);
+}
+
 // ---- src/merkle_tree_gadget.rs:183-325
 static void merkle_root_zero_leaves(size_t height, const uint8_t *root) {
   CircuitBuilder builder(CircuitConfig::standard_recursion_config());
@@ -258,10 +291,20 @@ static void test_read_u32_be_public_input() {
 // main.rs takes them from tree_hash_root(); the domain is compute_domain(DOMAIN_SYNC_COMMITTEE, Bellatrix fork
 // version, mainnet genesis_validators_root) -- with the BLS verifier stubbed any 32 bytes keep the circuit consistent.
 static void sha2(const uint8_t *l, const uint8_t *r, uint8_t *out) { orc_sha256_two_to_one(l, r, out); }
-enum LcVariant { LC_OK, LC_BAD_STATE_ROOT, LC_LOW_PARTICIPATION };
+enum LcVariant { LC_OK, LC_BAD_STATE_ROOT, LC_LOW_PARTICIPATION, LC_WITH_BLS_PROOF, LC_BLS_PROOF_OF_OTHER_BITS };
 static void light_client_update(LcVariant variant) {
+  // src/main.rs:170-176: the BLS-signature proof comes first (here: of the stand-in statement circuit), its common data shapes
+  // the recursive verifier inside the light-client circuit
+  const bool with_bls = variant == LC_WITH_BLS_PROOF || variant == LC_BLS_PROOF_OF_OTHER_BITS;
+  InnerProof bls;
+  BlsStatementStandIn bls_circuit;
+  CommonCircuitData bls_cd;
+  if (with_bls) {
+    bls_circuit = build_bls_statement_stand_in();
+    bls_cd = CommonCircuitData::of(bls_circuit.data->description());
+  }
   CircuitBuilder builder(CircuitConfig::standard_recursion_config());
-  ProofTarget target = add_virtual_proof_target(builder);
+  ProofTarget target = add_virtual_proof_target(builder, with_bls ? &bls_cd : nullptr);
   for (auto &limb : target.cur_state) builder.register_public_input(limb.t);  // src/main.rs:180-187
   for (auto &limb : target.new_state) builder.register_public_input(limb.t);
   builder.print_gate_counts(0);
@@ -305,6 +348,16 @@ static void light_client_update(LcVariant variant) {
                    LC634__FINALIZED_BODY_ROOT, LC634__FINALITY_BRANCH, cur_state, new_state, LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii,
                    new_i, new_ii, bits, LC634__NEXT_SYNC_COMMITTEE_BRANCH, LC633__NEXT_SYNC_COMMITTEE_PUBKEYS,
                    LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC634__SYNC_COMMITTEE_SIGNATURE, target);
+  if (with_bls) {
+    PartialWitness bpw;
+    std::vector<bool> proved_bits = bits;
+    if (variant == LC_BLS_PROOF_OF_OTHER_BITS) proved_bits[17] = !proved_bits[17];  // a proof about another participation set
+    set_bls_statement_stand_in(bpw, bls_circuit, signing_root, LC634__SYNC_COMMITTEE_SIGNATURE, LC633__NEXT_SYNC_COMMITTEE_PUBKEYS, proved_bits);
+    bls.data = std::move(bls_circuit.data);
+    prove_standalone(bls, bpw);
+    printf("BLS statement stand-in: 2^%u rows, %zu public inputs, %zu proof words\n", bls.data->degree_bits(), bls.proof.public_inputs.size(), bls.proof.proof.size());
+    set_bls_proof_target(pw, target, bls.proof, bls.digest, bls.cap);
+  }
   printf("light-client update 633 -> 634: participation %zu / 512, attested slot %llu (period %llu), state slot %llu -> %llu\n", participation,
          (unsigned long long)LC634__ATTESTED_SLOT, (unsigned long long)(LC634__ATTESTED_SLOT / 8192), (unsigned long long)LC633__FINALIZED_SLOT,
          (unsigned long long)LC634__FINALIZED_SLOT);
@@ -316,6 +369,10 @@ static void test_light_client_update() { light_client_update(LC_OK); }
 static void test_light_client_update_bad_state_root_panics() { light_client_update(LC_BAD_STATE_ROOT); }
 // src/targets.rs:304-332 update_validity and :184-235 find_sync_committee reject what they are there to reject
 static void test_light_client_update_low_participation_panics() { light_client_update(LC_LOW_PARTICIPATION); }
+// src/targets.rs:468-482 built as in the reference: the circuit verifies a proof with the BLS proof's 25 216 public inputs
+// recursively and ties them to the signing root, the signature, the committee and the participation bits
+static void test_light_client_update_with_recursive_proof() { light_client_update(LC_WITH_BLS_PROOF); }
+static void test_light_client_update_recursive_proof_of_other_bits_panics() { light_client_update(LC_BLS_PROOF_OF_OTHER_BITS); }
 
 // ---- the slot / participation gadgets on their own (src/targets.rs:184-235, :304-332, src/utils.rs:93-113)
 static void slot_h256(uint64_t slot, uint8_t out[32]) { memset(out, 0, 32); for (int i = 0; i < 8; i++) out[i] = (uint8_t)(slot >> (8 * i)); }
@@ -373,12 +430,6 @@ static void test_update_validity_threshold_not_exceeded_panics() { update_validi
 // ---- the recursive verifier (src/targets.rs:468-482, src/main.rs:172-176: add_virtual_proof_with_pis + verify_proof of an inner
 // proof whose public inputs are connected into the outer circuit; the reference's inner proof is the BLS-signature verifier,
 // which does not exist here: the inner circuit below is a stand-in with the same interface - a proof with public inputs)
-struct InnerProof {
-  std::unique_ptr<CircuitData> data;
-  ProofWithPublicInputs proof;
-  uint64_t digest[4];
-  std::vector<uint64_t> cap;
-};
 // inner circuit: public inputs (x, y, x * y + x, low 16 bits of y recomposed) and, optionally, one two_to_one_sha256
 static InnerProof prove_inner(bool with_sha, F x_val, F y_val) {
   InnerProof in;
@@ -398,29 +449,7 @@ static InnerProof prove_inner(bool with_sha, F x_val, F y_val) {
   PartialWitness pw;
   pw.set_target(x, x_val); pw.set_target(y, y_val);
   if (with_sha) { pw.set_hash256_target(l, ZERO_ROOT_2); pw.set_hash256_target(r, ZERO_ROOT_4); }
-  const CircuitDescription &D = in.data->description();
-  if (g_gpu) {
-    in.data->attach_gpu(g_ctx);
-    in.proof = in.data->prove(pw);
-    in.data->verify(in.proof);
-    in.data->verifier_only_data(in.digest, in.cap);
-  } else {  // the oracle is the CPU prover of the tests
-    std::vector<uint64_t> wires;
-    in.data->generate_witness(pw, wires, in.proof.public_inputs);
-    orc_params op;
-    memcpy(&op, &D.params, sizeof op);
-    std::vector<orc_gate> og(D.gates.size());
-    memcpy(og.data(), D.gates.data(), og.size() * sizeof(orc_gate));
-    orc_circuit *oc = orc_circuit_new(&op, D.constants_sigmas.data(), D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(),
-                                      D.imm.data(), D.imm.size(), D.num_public_inputs);
-    if (!oc) throw std::runtime_error("oracle rejected the inner circuit");
-    in.proof.proof.resize(orc_proof_words(&op));
-    orc_prove(oc, wires.data(), in.proof.public_inputs.data(), in.proof.proof.data());
-    if (orc_verify(oc, in.proof.proof.data(), in.proof.public_inputs.data()) != 0) throw std::runtime_error("oracle verifier rejected the inner proof");
-    in.cap.resize((size_t)4 << D.params.cap_height);
-    orc_circuit_digest(oc, in.digest, in.cap.data());
-    orc_circuit_free(oc);
-  }
+  prove_standalone(in, pw);
   return in;
 }
 // outer circuit: verify_proof(inner) with the inner public inputs re-exported; `tamper`: the word of the inner proof to corrupt
@@ -484,6 +513,8 @@ static const TestCase TESTS[] = {
     {"test_light_client_update", test_light_client_update, false},
     {"test_light_client_update_bad_state_root_panics", test_light_client_update_bad_state_root_panics, true},
     {"test_light_client_update_low_participation_panics", test_light_client_update_low_participation_panics, true},
+    {"test_light_client_update_with_recursive_proof", test_light_client_update_with_recursive_proof, false},
+    {"test_light_client_update_recursive_proof_of_other_bits_panics", test_light_client_update_recursive_proof_of_other_bits_panics, true},
     {"test_find_sync_committee_current_period", test_find_sync_committee_current_period, false},
     {"test_find_sync_committee_next_period", test_find_sync_committee_next_period, false},
     {"test_find_sync_committee_stale_period_panics", test_find_sync_committee_stale_period_panics, true},

@@ -11,6 +11,7 @@ CPU_TESTS = [
     "test_contract_state", "test_verify_sync_committee_branch", "test_verify_sync_committee_branch_panics",
     "test_read_u32_be_public_input", "test_ssz_sync_committee", "test_light_client_update",
     "test_light_client_update_bad_state_root_panics", "test_light_client_update_low_participation_panics",
+    "test_light_client_update_with_recursive_proof", "test_light_client_update_recursive_proof_of_other_bits_panics",
     "test_find_sync_committee_current_period", "test_find_sync_committee_next_period",
     "test_find_sync_committee_stale_period_panics", "test_find_sync_committee_previous_period_panics",
     "test_slot_connect_rejects_wide_encoding_panics", "test_update_validity", "test_update_validity_equal_slots_and_343",
