@@ -30,7 +30,16 @@ extern const uint32_t GATE_DEGREE[G_COUNT];
 
 // ---- Goldilocks on the host (circuit construction / witness generation only)
 inline F f_add(F a, F b) { F s = a + b; return (s < a || s >= GOLDILOCKS_P) ? s - GOLDILOCKS_P : s; }
-inline F f_mul(F a, F b) { return (F)((unsigned __int128)a * b % GOLDILOCKS_P); }
+inline F f_mul(F a, F b) {  // 2^64 = 2^32 - 1 and 2^96 = -1 (mod p): no 128-bit division
+  const unsigned __int128 m = (unsigned __int128)a * b;
+  const uint64_t lo = (uint64_t)m, hi = (uint64_t)(m >> 64), hi_hi = hi >> 32, hi_lo = hi & 0xFFFFFFFFull;
+  uint64_t t = lo - hi_hi;
+  if (lo < hi_hi) t -= 0xFFFFFFFFull;
+  const uint64_t u = (hi_lo << 32) - hi_lo;
+  uint64_t r = t + u;
+  if (r < t) r += 0xFFFFFFFFull;
+  return r >= GOLDILOCKS_P ? r - GOLDILOCKS_P : r;
+}
 inline F f_pow(F b, uint64_t e) { F r = 1; while (e) { if (e & 1) r = f_mul(r, b); b = f_mul(b, b); e >>= 1; } return r; }
 inline F f_root_of_unity(unsigned bits) { return f_pow(f_pow(7, (GOLDILOCKS_P - 1) >> 32), 1ull << (32 - bits)); }
 

@@ -111,7 +111,7 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     int rc = lcp2_verify(vc, oproof.data(), oproof.size(), pis.data(), pis.size(), &failed);
     lcp2_circuit_destroy(vc);
     if (rc != LCP2_OK) throw std::runtime_error("product verifier rejected the oracle proof, check " + std::to_string(failed));
-    printf("proved (oracle) and verified, degree_bits %u\n", data.degree_bits());
+    printf("proved (oracle) and verified, degree_bits %u (host witness generation %lld ms)\n", data.degree_bits(), witness_ms);
   }
   orc_circuit_free(oc);
 }
