@@ -98,7 +98,7 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     if (!oproof.empty() && proof.proof != oproof) throw std::runtime_error("GPU proof differs from the oracle proof");
     if (need_built && orc_verify(oc, proof.proof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the GPU proof");
   } else if (oproof.empty()) {
-    printf("witness generated and every gate constraint checked (oracle), degree_bits %u\n", data.degree_bits());
+    printf("witness generated (host, %lld ms) and every gate constraint checked (oracle), degree_bits %u\n", witness_ms, data.degree_bits());
   } else {
     // product host verifier on the oracle's proof (verifier-only circuit: digest + cap from the oracle's build)
     uint64_t digest[4];

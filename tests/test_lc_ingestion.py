@@ -118,3 +118,15 @@ def test_lc_prover_end_to_end_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert len(re.findall(r"proof \d: proved in", r.stdout)) == 2
     print(r.stdout)
+
+
+@pytest.mark.gpu
+def test_lc_prover_with_recursive_proof_gpu(tmp_path):
+    """the same with src/targets.rs:468-482 built in: an inner proof with the BLS proof's 25 216 public inputs (stand-in statement
+    circuit) is produced, then verified recursively inside the light-client circuit, whose proof the host verifier accepts"""
+    _, files = _files(tmp_path, "fixture")
+    r = cpp_build.run_example(files + ["--repeat", "1", "--bls-proof-stand-in"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "25216 public inputs" in r.stdout and len(re.findall(r"proof \d: proved in", r.stdout)) == 1
+    gates = int(re.search(r"(\d+) gates", r.stdout).group(1))
+    assert gates > 335000  # the recursive verifier's PoseidonGate and ArithmeticGate rows are in the circuit
