@@ -19,6 +19,7 @@
 #include <string>
 #include "../../eth-lc-plonky2_amd/host/gadgets.hpp"
 #include "../../eth-lc-plonky2_amd/host/recursion.hpp"
+#include "../../oracle/oracle.h"
 #include "../../oracle/plonk.h"
 #include "golden_data.hpp"
 
@@ -427,6 +428,58 @@ static void test_update_validity_equal_slots_and_343() { update_validity(7, 7, F
 static void test_update_validity_finalized_before_current_panics() { update_validity(LC634__FINALIZED_SLOT, LC633__FINALIZED_SLOT, 428); }
 static void test_update_validity_threshold_not_exceeded_panics() { update_validity(1, 2, FINALITY_THRESHOLD); }
 
+// ---- the builder primitives the recursive verifier is made of, against native values: is_equal / inverse / and / or, one
+// PoseidonGate row with and without the swap, hash_n_to_hash_no_pad and a Merkle path against the oracle's Poseidon
+static void builder_primitives(bool break_it) {
+  CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+  Target a = builder.add_virtual_target(), b = builder.add_virtual_target();
+  BoolTarget eq_ab = builder.is_equal(a, b), eq_aa = builder.is_equal(a, a);
+  Target inv = builder.inverse(a);
+  BoolTarget o = builder.or_(eq_ab, eq_aa), n = builder.and_(eq_ab, eq_aa);
+  std::array<Target, 12> st;
+  for (auto &t : st) t = builder.add_virtual_target();
+  BoolTarget sw = builder.add_virtual_bool_target_safe();
+  std::array<Target, 12> out0 = builder.poseidon(st), out1 = builder.poseidon(st, sw);
+  std::vector<Target> msg;
+  for (int i = 0; i < 19; i++) msg.push_back(builder.add_virtual_target());
+  std::array<Target, 4> h = hash_n_to_hash_no_pad(builder, msg);
+  for (Target t : {eq_ab.target, eq_aa.target, inv, o.target, n.target}) builder.register_public_input(t);
+  for (Target t : out0) builder.register_public_input(t);
+  for (Target t : out1) builder.register_public_input(t);
+  for (Target t : h) builder.register_public_input(t);
+  auto data = builder.build();
+  PartialWitness pw;
+  const F av = 0x1234567890abcdefull % GOLDILOCKS_P, bv = 77;
+  pw.set_target(a, av); pw.set_target(b, bv);
+  uint64_t s0[12], s1[12], m[19], want_h[4];
+  for (int i = 0; i < 12; i++) { s0[i] = (0x9e3779b97f4a7c15ull * (i + 3)) % GOLDILOCKS_P; pw.set_target(st[i], s0[i]); }
+  for (int i = 0; i < 12; i++) s1[i] = i < 4 ? s0[i + 4] : i < 8 ? s0[i - 4] : s0[i];  // the swap exchanges the two digests
+  pw.set_bool_target(sw, true);
+  for (int i = 0; i < 19; i++) { m[i] = (0xc2b2ae3d27d4eb4full * (i + 1)) % GOLDILOCKS_P; pw.set_target(msg[i], m[i]); }
+  std::vector<uint64_t> wires;
+  std::vector<F> pis;
+  data->generate_witness(pw, wires, pis);
+  orc_poseidon_permute(s0); orc_poseidon_permute(s1);
+  orc_hash_no_pad(m, 19, want_h);
+  unsigned __int128 prod = (unsigned __int128)pis[2] * av % GOLDILOCKS_P;
+  bool ok = pis[0] == 0 && pis[1] == 1 && prod == 1 && pis[3] == 1 && pis[4] == 0;
+  for (int i = 0; i < 12; i++) ok = ok && pis[5 + i] == s0[i] && pis[17 + i] == s1[i];
+  for (int i = 0; i < 4; i++) ok = ok && pis[29 + i] == want_h[i];
+  if (!ok) throw std::runtime_error("builder primitives: a public input differs from the native value");
+  if (break_it) {  // inverse(0) has no witness
+    PartialWitness bad;
+    bad.set_target(a, 0); bad.set_target(b, bv);
+    for (int i = 0; i < 12; i++) bad.set_target(st[i], 1);
+    bad.set_bool_target(sw, false);
+    for (int i = 0; i < 19; i++) bad.set_target(msg[i], 2);
+    prove_and_verify(*data, bad);
+    return;
+  }
+  prove_and_verify(*data, pw);
+}
+static void test_builder_primitives() { builder_primitives(false); }
+static void test_builder_inverse_of_zero_panics() { builder_primitives(true); }
+
 // ---- the recursive verifier (src/targets.rs:468-482, src/main.rs:172-176: add_virtual_proof_with_pis + verify_proof of an inner
 // proof whose public inputs are connected into the outer circuit; the reference's inner proof is the BLS-signature verifier,
 // which does not exist here: the inner circuit below is a stand-in with the same interface - a proof with public inputs)
@@ -524,6 +577,8 @@ static const TestCase TESTS[] = {
     {"test_update_validity_equal_slots_and_343", test_update_validity_equal_slots_and_343, false},
     {"test_update_validity_finalized_before_current_panics", test_update_validity_finalized_before_current_panics, true},
     {"test_update_validity_threshold_not_exceeded_panics", test_update_validity_threshold_not_exceeded_panics, true},
+    {"test_builder_primitives", test_builder_primitives, false},
+    {"test_builder_inverse_of_zero_panics", test_builder_inverse_of_zero_panics, true},
     {"test_recursive_verifier", test_recursive_verifier, false},
     {"test_recursive_verifier_constant_verifier_data_sha_inner", test_recursive_verifier_constant_verifier_data_sha_inner, false},
     {"test_recursive_verifier_tampered_opening_panics", test_recursive_verifier_tampered_opening_panics, true},

@@ -18,6 +18,7 @@ CPU_TESTS = [
     "test_update_validity_finalized_before_current_panics", "test_update_validity_threshold_not_exceeded_panics",
     # the recursive verifier gadget (host/recursion.cpp): an inner proof checked natively and in-circuit; each tampered word
     # (opening, cap, leaf, FRI evaluation, final polynomial, PoW witness, Merkle sibling, public input, digest) must fail
+    "test_builder_primitives", "test_builder_inverse_of_zero_panics",
     "test_recursive_verifier", "test_recursive_verifier_constant_verifier_data_sha_inner",
     "test_recursive_verifier_tampered_opening_panics", "test_recursive_verifier_tampered_cap_panics",
     "test_recursive_verifier_tampered_leaf_panics", "test_recursive_verifier_tampered_fri_layer_panics",
