@@ -31,6 +31,74 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassParams p) {
   pass.template store<INV>(lds, tid, NTT_THREADS, wg, col, z);
 }
 
+// Workgroup barrier that orders LDS accesses only: the global loads of a prefetch and the stores of the previous slab stay in
+// flight across it (__syncthreads() would drain the stores: its release fence waits vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// The passes of a large transform (2^13-element slabs: 3 + 3 + 3 strided bits over 16-element runs, or 3 + 3 + 3 + 4 contiguous
+// bits) with SEVERAL slabs per workgroup and the next slab's elements prefetched into registers while the current one is in its
+// register steps: with two workgroups per CU (the slab fills the LDS) nothing else hides the HBM latency of the load phase,
+// which costs 18 % of the LDE when exposed.  FACTORS: the load multiplies by a one-level factor table (the coset scale of an
+// LDE's first pass, the inter-group twiddle of an inverse strided pass).
+template <bool INV, bool STRIDED, bool FACTORS>
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p, u32 gx, u32 gy, u32 gz, u32 slabs_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  NttPass pass{p};
+  const u32 tid = threadIdx.x;
+  auto coords = [&](u32 it, u32 &wg, u32 &col, u32 &z) {  // the slab of iteration `it`: the block mapping of k_ntt_pass
+    const u32 lin = blockIdx.x + it * gridDim.x;
+    if (p.xcd_group) {
+      const u32 x = lin & 7, j = lin >> 3, sc = (j / gz) * 8 + x;
+      z = j % gz + p.z_base; wg = sc % gx; col = sc / gx;
+    } else {
+      wg = lin % gx; col = (lin / gx) % gy; z = lin / (gx * gy) + p.z_base;
+    }
+  };
+  u64 v[16];
+  u32 wg, col, z;
+  coords(0, wg, col, z);
+  pass.prefetch(tid, NTT_THREADS, wg, col, z, v);
+  for (u32 it = 0; it < slabs_per_wg; it++) {
+    pass.template commit<INV, FACTORS>(lds, tid, NTT_THREADS, wg, z, v);
+    lds_barrier();
+    u32 nwg = wg, ncol = col, nz = z;
+    if (it + 1 < slabs_per_wg) {
+      coords(it + 1, nwg, ncol, nz);
+      pass.prefetch(tid, NTT_THREADS, nwg, ncol, nz, v);
+    }
+    if (STRIDED) {  // S = 4, B = 9: steps of 3 bits at local bits 10, 7, 4
+      if (!INV) {
+        pass.template step_r<false, 3, 10>(lds, tid, NTT_THREADS, 8); lds_barrier();
+        pass.template step_r<false, 3, 7>(lds, tid, NTT_THREADS, 5); lds_barrier();
+        pass.template step_r<false, 3, 4>(lds, tid, NTT_THREADS, 2); lds_barrier();
+      } else {
+        pass.template step_r<true, 3, 4>(lds, tid, NTT_THREADS, 2); lds_barrier();
+        pass.template step_r<true, 3, 7>(lds, tid, NTT_THREADS, 5); lds_barrier();
+        pass.template step_r<true, 3, 10>(lds, tid, NTT_THREADS, 8); lds_barrier();
+      }
+    } else {        // S = 0, B = 13: 3 + 3 + 3 bits at 10, 7, 4 and the 4 bottom bits
+      if (!INV) {
+        pass.template step_r<false, 3, 10>(lds, tid, NTT_THREADS, 12); lds_barrier();
+        pass.template step_r<false, 3, 7>(lds, tid, NTT_THREADS, 9); lds_barrier();
+        pass.template step_r<false, 3, 4>(lds, tid, NTT_THREADS, 6); lds_barrier();
+        pass.template step_r<false, 4, 0>(lds, tid, NTT_THREADS, 3); lds_barrier();
+      } else {
+        pass.template step_r<true, 4, 0>(lds, tid, NTT_THREADS, 3); lds_barrier();
+        pass.template step_r<true, 3, 4>(lds, tid, NTT_THREADS, 6); lds_barrier();
+        pass.template step_r<true, 3, 7>(lds, tid, NTT_THREADS, 9); lds_barrier();
+        pass.template step_r<true, 3, 10>(lds, tid, NTT_THREADS, 12); lds_barrier();
+      }
+    }
+    pass.template store<INV>(lds, tid, NTT_THREADS, wg, col, z);
+    lds_barrier();  // the slab has been read out: the next commit may overwrite it
+    wg = nwg; col = ncol; z = nz;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bitrev_tile(BitrevTile b) {
   __shared__ u64 lds[64 * 65];
   b.load(lds, threadIdx.x, 256, blockIdx.x, blockIdx.y);
@@ -45,8 +113,33 @@ __global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restri
     out[(u64)col * os + bitrev32(i, lg)] = gl_canon(in[(u64)col * is + i]);
 }
 
+
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
   size_t lds_bytes = (size_t)8 * ntt_lds_words(p.L);
+  // the prefetching form: the slab shapes of a large transform, factors (if any) from one-level tables, and enough slabs that
+  // the shorter grid still fills the chip
+  const u64 total = (u64)wgs * cols * nz;
+  const bool strided = p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333;
+  const bool contiguous = p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0;
+  const bool factor = inverse ? p.g_lo != 0 : p.scale_mode != 0;
+  const bool direct = inverse ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT);
+  // (forward passes only: the inverse instantiations need 30-odd more VGPRs than the 128 of four waves per SIMD and lose to the
+  // plain kernel once they spill)
+  if (!inverse && (strided || contiguous) && (!factor || (direct && strided)) && total < (1ull << 31)) {
+    // slabs per workgroup: only the first load of a workgroup is exposed, so as many as still leave 2048 workgroups (4 rounds
+    // of the 512 resident ones) and divide the slab count into a multiple of 8 workgroups (the XCD mapping)
+    u32 spw = 0;
+    for (u32 k = 16; k >= 2 && !spw; k >>= 1)
+      if (total % (k * 8) == 0 && total / k >= 2048) spw = k;
+    if (spw) {
+      const dim3 grid((u32)(total / spw));
+#define LCP2_PF(INV, STR, FAC) hipLaunchKernelGGL((k_ntt_pass_pf<INV, STR, FAC>), grid, dim3(NTT_THREADS), lds_bytes, s, p, wgs, cols, nz, spw)
+      if (strided) { if (factor) LCP2_PF(false, true, true); else LCP2_PF(false, true, false); }
+      else LCP2_PF(false, false, false);
+#undef LCP2_PF
+      return;
+    }
+  }
   dim3 grid(wgs, cols, nz);
   if (inverse) hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds_bytes, s, p);
   else hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), lds_bytes, s, p);

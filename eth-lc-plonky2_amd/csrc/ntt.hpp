@@ -250,6 +250,38 @@ struct NttPass {
     }
   }
 
+  // The load phase in two halves for the prefetching kernel (kernels_ntt.hip k_ntt_pass_pf): `prefetch` issues the loads of a
+  // thread's 16 elements of a 2^13 slab into registers and returns, `commit` turns them into the canonical, pre-multiplied LDS
+  // image.  Same addressing as the constant-stride walk of load().  The one-level factors are fetched in commit, 8 at a time
+  // (the tables are shared by every column and mostly cache resident; holding them across the register steps as well would
+  // cost 32 more VGPRs than the kernel has).
+  LCP2_HD void prefetch(u32 tid, u32 nthr, u32 wg, u32 col, u32 z, u64 *v) const {
+    const u64 *src = p.in + (u64)col * p.in_col_stride + (u64)z * p.in_z_stride;
+    const u64 g0 = global_index(wg, tid), gs = (u64)(nthr >> p.S) << p.g_lo;
+#pragma unroll
+    for (u32 j = 0; j < 16; j++) v[j] = src[g0 + j * gs];
+  }
+  template <bool INV, bool FACTORS>
+  LCP2_HD void commit(u64 *lds, u32 tid, u32 nthr, u32 wg, u32 z, const u64 *v) const {
+    const u32 ph0 = lds_phys(tid), ps = nthr + (nthr >> 4);
+    if (FACTORS) {
+      const u64 gs = (u64)(nthr >> p.S) << p.g_lo;
+      const u64 *fac = INV ? p.tw.lo + (((u64)((tid >> p.S) & ((1u << p.B) - 1)) << p.g_lo) | low_bits(wg, tid))
+                           : p.sc.lo + (u64)z * p.sc_lo_z_stride + global_index(wg, tid);
+#pragma unroll
+      for (u32 h = 0; h < 16; h += 8) {
+        u64 f[8];
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) f[j] = fac[(h + j) * gs];
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) lds[ph0 + (h + j) * ps] = gl_mul(v[h + j], f[j]);
+      }
+    } else {
+#pragma unroll
+      for (u32 j = 0; j < 16; j++) lds[ph0 + j * ps] = gl_canon(v[j]);
+    }
+  }
+
   // Register step over the RB group bits whose top one is kb_top (group-relative): see the header comment.
   // PC: the local bit position P of the step's lowest bit when it is known at compile time (-1: runtime).  For P >= 4 the padded
   // LDS word of element j is word(base) + j * (2^P + 2^(P-4)), for the bottom step (P = 0, 16 elements) word(base) + j: with
