@@ -218,7 +218,12 @@ def main():
     if world > 1 or a.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # a rank that fails inside the sharded side measurement must not take the bench line with it: collectives raise after the
+        # timeout instead of the watchdog aborting every rank (the replica measurement itself uses one barrier and one all-reduce)
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream(dev)
