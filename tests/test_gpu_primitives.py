@@ -73,6 +73,22 @@ def test_lde_parity(gpu_ctx, oracle, lg, ncols):
     assert (got == lde_leaf_order(oracle, c % np.uint64(P), 3)).all()
 
 
+def test_lde_headline_size_parity(gpu_ctx, oracle):
+    """The LDE of the headline run: 2^22 coefficients, rate 8 - the strided pass over 16-element runs with the coset scale table,
+    then the contiguous pass, both in the prefetching multi-slab kernel (csrc/kernels_ntt.hip k_ntt_pass_pf).  One column against
+    the oracle; the slab count decides how many slabs a workgroup chains (2 for one column, 8 for four, 16 for eight), so the
+    batched results must equal the single-column ones."""
+    rng = np.random.default_rng(2222)
+    c = rand_field(rng, (8, 1 << 22), canonical=False)
+    one = gpu_ctx.lde_batch(c[0:1], 3)
+    assert (one == lde_leaf_order(oracle, c[0:1] % np.uint64(P), 3)).all()
+    four = gpu_ctx.lde_batch(c[0:4], 3)
+    assert (four[0] == one[0]).all()
+    eight = gpu_ctx.lde_batch(c, 3)
+    assert (eight[0:4] == four).all()
+    assert (eight[6] == gpu_ctx.lde_batch(c[6:7], 3)[0]).all()
+
+
 def test_ntt_large_roundtrip_and_linearity(gpu_ctx):
     # full-size property test (n = 2^22, the BASELINE degree): inverse(forward(x)) = x, and NTT(a+b) = NTT(a)+NTT(b)
     rng = np.random.default_rng(22)
