@@ -157,6 +157,27 @@ std::array<Target, 2> CircuitBuilder::hint_split_32(Target x) {
   impl_->d->ops.push_back(op);
   return out;
 }
+std::vector<Target> CircuitBuilder::hint(const std::vector<Target> &inputs, size_t num_outputs, std::function<void(const std::vector<F> &, std::vector<F> &)> fn) {
+  Op op; op.kind = Op::HINT; op.hint_fn = std::move(fn);
+  for (Target t : inputs) op.hint_in.push_back(t.id);
+  std::vector<Target> out;
+  for (size_t i = 0; i < num_outputs; i++) { out.push_back(add_virtual_target()); op.internal.push_back(out.back().id); }
+  impl_->d->ops.push_back(std::move(op));
+  return out;
+}
+CircuitBuilder::CanonicalSplit CircuitBuilder::split_canonical(Target x, uint32_t hi_bits) {
+  if (hi_bits < 1 || hi_bits > 32) throw std::runtime_error("split_canonical: 1..32 high bits");
+  std::array<Target, 2> h = hint_split_32(x);
+  CanonicalSplit r{h[0], h[1], split_le(h[0], 32)};
+  std::vector<BoolTarget> hi = split_le(h[1], hi_bits);
+  connect(arithmetic(1ull << 32, h[1], one(), 1, h[0]), x);
+  if (hi_bits == 32) {
+    BoolTarget top = is_equal(h[1], constant(0xFFFFFFFFull));
+    connect(mul(top.target, h[0]), zero());
+  }
+  r.bits.insert(r.bits.end(), hi.begin(), hi.end());
+  return r;
+}
 std::array<Target, 12> CircuitBuilder::poseidon(const std::array<Target, 12> &inputs, BoolTarget swap) {
   Impl *b = impl_.get();
   const uint32_t row = b->new_row(G_POSEIDON);
@@ -461,6 +482,7 @@ static bool host_op_ready(const Op &op, const Values &V) {
   switch (op.kind) {
     case Op::ARITH: return has(op.x) && has(op.y) && has(op.z);
     case Op::BITS: case Op::INV: case Op::SPLIT32: return has(op.x);
+    case Op::HINT: { for (uint32_t v : op.hint_in) if (!has(v)) return false; return true; }
     case Op::EXT_INV: return has(op.x) && has(op.y);
     case Op::POSEIDON: { if (!has(op.x)) return false; for (int i = 0; i < 12; i++) if (!has(op.in[i])) return false; return true; }
     case Op::SHA: { for (uint32_t v : op.in) if (!has(v)) return false; return true; }
@@ -488,6 +510,13 @@ static void host_op_eval(const Op &op, Values &V, std::vector<lcp2_cell> &raw) {
       break;
     }
     case Op::SPLIT32: { F x = V.get(op.x, "split input"); V.set(op.internal[0], x & 0xFFFFFFFFull, "low half"); V.set(op.internal[1], x >> 32, "high half"); break; }
+    case Op::HINT: {
+      std::vector<F> in, out(op.internal.size(), 0);
+      for (uint32_t v : op.hint_in) in.push_back(V.get(v, "hint input"));
+      op.hint_fn(in, out);
+      for (size_t i = 0; i < out.size(); i++) V.set(op.internal[i], out[i] % GOLDILOCKS_P, "hint output");
+      break;
+    }
     case Op::SHA: break;  // the caller's
   }
 }

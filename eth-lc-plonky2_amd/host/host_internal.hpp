@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include "lc_plonky2.hpp"
 
 namespace lc {
@@ -48,16 +49,20 @@ extern const uint32_t SHA_IV[8];
 
 // one generator step, evaluated in creation order by generate_witness
 struct Op {
-  enum Kind { CONST, ARITH, SHA, BITS, POSEIDON, INV, EXT_INV, SPLIT32 } kind;
+  enum Kind { CONST, ARITH, SHA, BITS, POSEIDON, INV, EXT_INV, SPLIT32, HINT } kind;
   // BITS: x -> its c0 low bits in `internal` (split_le), fails if x does not fit
   // POSEIDON: in[0..12), swap flag x -> internal[0..12) on row first_row
   // INV: x -> out = 1 / x (0 for 0) ; EXT_INV: (x, y) -> internal[0..2) ; SPLIT32: x -> internal = {low 32 bits, high 32 bits}
+  // HINT: hint_in -> internal through hint_fn (a generator without constraints of its own, e.g. the quotient and remainder of a
+  //       BigUint division; the gadget that adds it constrains the results)
   uint32_t out = 0, x = 0, y = 0, z = 0;  // CONST: out ; ARITH: x, y, z -> out
   F c0 = 0, c1 = 0;                        // CONST: c0 = value
   // SHA: message words in[16] -> digest out8[8]; internal words by row
   std::array<uint32_t, 16> in{};
   std::array<uint32_t, 8> out8{};
   uint32_t first_row = 0;
+  std::vector<uint32_t> hint_in;
+  std::function<void(const std::vector<F> &, std::vector<F> &)> hint_fn;
   std::vector<uint32_t> internal;          // vars: sched W[16..64) (48), then per compression c, per round t: t1, a_new, e_new (2*64*3), then mid[8]
 };
 

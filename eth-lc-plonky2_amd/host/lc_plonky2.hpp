@@ -13,6 +13,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -103,6 +104,12 @@ class CircuitBuilder {
   // and the canonical value of x as low / high 32-bit halves
   std::array<Target, 2> hint_ext_inverse(Target x0, Target x1);
   std::array<Target, 2> hint_split_32(Target x);
+  // a generator of the caller's: outputs = fn(inputs), no constraints (SimpleGenerator without a gate)
+  std::vector<Target> hint(const std::vector<Target> &inputs, size_t num_outputs, std::function<void(const std::vector<F> &, std::vector<F> &)> fn);
+  // the CANONICAL value of x as 32 low bits and hi_bits high bits (x = lo + 2^32 hi, both range checked, and hi = 2^32 - 1 forces
+  // lo = 0: no second decomposition exists).  hi_bits < 32 also bounds x < 2^(32 + hi_bits).
+  struct CanonicalSplit { Target lo, hi; std::vector<BoolTarget> bits; };
+  CanonicalSplit split_canonical(Target x, uint32_t hi_bits = 32);
   BoolTarget not_(BoolTarget b);                         // builder.not(b) = 1 - b
   Target select(BoolTarget b, Target x, Target y);       // builder._if / select: b ? x : y
   void assert_bool(BoolTarget b);                        // b * b = b

@@ -104,21 +104,6 @@ struct Ar {
   }
 };
 
-// canonical little-endian bits of a field element: low and high 32-bit halves, each range checked, x = lo + 2^32 hi, and
-// hi = 2^32 - 1 forces lo = 0 (the only way a second, non-canonical decomposition could exist).  hi_bits < 32 additionally
-// bounds the value (the proof-of-work check: the leading 64 - 32 - hi_bits bits are zero).
-std::vector<BoolTarget> canonical_bits(CircuitBuilder &B, Target x, uint32_t hi_bits = 32) {
-  std::array<Target, 2> h = B.hint_split_32(x);
-  std::vector<BoolTarget> lo = B.split_le(h[0], 32);
-  std::vector<BoolTarget> hi = B.split_le(h[1], hi_bits);
-  B.connect(B.arithmetic(1ull << 32, h[1], B.one(), 1, h[0]), x);
-  if (hi_bits == 32) {
-    BoolTarget top = B.is_equal(h[1], B.constant(0xFFFFFFFFull));
-    B.connect(B.mul(top.target, h[0]), B.zero());
-  }
-  lo.insert(lo.end(), hi.begin(), hi.end());
-  return lo;
-}
 }  // namespace
 
 // ------------------------------------------------------------------ hashing gadgets
@@ -356,7 +341,7 @@ void verify_proof(CircuitBuilder &B, const ProofWithPublicInputsTarget &pt, cons
   ch.observe_element(pr[L.pow_witness]);
   // fri_proof_of_work: the leading proof_of_work_bits of the response are zero
   if (p.proof_of_work_bits < 1 || p.proof_of_work_bits > 31) throw std::runtime_error("verify_proof: proof_of_work_bits out of range");
-  canonical_bits(B, ch.get_challenge(), 32 - p.proof_of_work_bits);
+  B.split_canonical(ch.get_challenge(), 32 - p.proof_of_work_bits);
 
   // ---- vanishing(zeta) = Z_H(zeta) * t(zeta)
   std::vector<EV> ow(W), oc(NC + NR);
@@ -417,7 +402,7 @@ void verify_proof(CircuitBuilder &B, const ProofWithPublicInputsTarget &pt, cons
   const std::vector<Target> caps[4] = {vd.constants_sigmas_cap, span(L.wires_cap, L.cap_words), span(L.zs_cap, L.cap_words), span(L.quot_cap, L.cap_words)};
   const F wN = f_root_of_unity(lgN);
   for (uint32_t q = 0; q < p.num_query_rounds; q++) {
-    std::vector<BoolTarget> xbits = canonical_bits(B, ch.get_challenge());
+    std::vector<BoolTarget> xbits = B.split_canonical(ch.get_challenge()).bits;
     xbits.resize(lgN);  // x_index = challenge mod 2^lgN
     const size_t R = L.queries + (size_t)q * L.query_words;
     for (int o = 0; o < 4; o++)

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 HOST = os.path.join(ROOT, "eth-lc-plonky2_amd", "host")
 BIN = os.path.join(CPP, "test_gadgets")
-HOST_SOURCES = ("gates.cpp", "builder.cpp", "gadgets.cpp", "light_client_update.cpp", "poseidon_host.cpp", "recursion.cpp")
+HOST_SOURCES = ("gates.cpp", "builder.cpp", "gadgets.cpp", "light_client_update.cpp", "poseidon_host.cpp", "recursion.cpp", "biguint.cpp")
 EXAMPLE_SRC = os.path.join(ROOT, "examples", "lc_prover.cpp")
 EXAMPLE_BIN = os.path.join(ROOT, "examples", "lc_prover")
 

@@ -18,6 +18,10 @@ CPU_TESTS = [
     "test_update_validity_finalized_before_current_panics", "test_update_validity_threshold_not_exceeded_panics",
     # the recursive verifier gadget (host/recursion.cpp): an inner proof checked natively and in-circuit; each tampered word
     # (opening, cap, leaf, FRI evaluation, final polynomial, PoW witness, Merkle sibling, public input, digest) must fail
+    # BigUint gadgets (host/biguint.cpp): the reference's plonky2_crypto biguint surface and its two BigUint sub-circuits
+    "test_biguint_arithmetic", "test_biguint_arithmetic_all_ones", "test_biguint_division_by_zero_panics", "test_biguint_hash256_connect",
+    "test_find_sync_committee_big_current_period", "test_find_sync_committee_big_next_period", "test_find_sync_committee_big_stale_period_panics",
+    "test_update_validity_big", "test_update_validity_big_finalized_before_current_panics", "test_update_validity_big_threshold_not_exceeded_panics",
     "test_builder_primitives", "test_builder_inverse_of_zero_panics",
     "test_recursive_verifier", "test_recursive_verifier_constant_verifier_data_sha_inner",
     "test_recursive_verifier_tampered_opening_panics", "test_recursive_verifier_tampered_cap_panics",
