@@ -8,6 +8,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("OMP_NUM_THREADS", "16")  # the oracle's OpenMP regions: a GPU box shows more hardware threads than the job may use
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,6 +35,7 @@ for r in range(rounds):
             print("MISMATCH proof", r, db, rep, int(np.nonzero(got != want)[0][0]))
     data.close()
     oc.close()
+    print("round %d: degree_bits %d ok (%.1f s so far)" % (r, db, time.time() - t0), flush=True)
 print("proofs: %d rounds, %d mismatches, %.1f s" % (rounds, bad, time.time() - t0))
 rng = np.random.default_rng(99)
 P = m.GOLDILOCKS_P
@@ -45,14 +48,15 @@ for rep in range(4):
     if not (got == want).all():
         bad += 1
         print("MISMATCH poseidon batch", rep)
-print("poseidon: 4 x 2^18 permutations of arbitrary u64 states compared")
-for lg in (10, 13, 14, 16, 18):
+print("poseidon: 4 x 2^18 permutations of arbitrary u64 states compared", flush=True)
+for lg in (10, 13, 14, 16, 18, 20):
     cols = rng.integers(0, P, size=(3, 1 << lg), dtype=np.uint64)
     got = ctx.lde_batch(cols, 3)
     want = oracle_lib.lde_leaf_order(L, cols, 3, 7)
     if not (np.asarray(got) == np.asarray(want)).all():
         bad += 1
         print("MISMATCH lde", lg)
-print("lde: sizes 2^10..2^18 compared")
+    print("lde 2^%d ok" % lg, flush=True)
+print("lde: sizes 2^10..2^20 compared")
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
