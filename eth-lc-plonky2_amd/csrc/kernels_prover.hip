@@ -651,6 +651,53 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_perm(QuotientArgs a, 
     if (c < CH) a.out[(u64)c * a.N + ig] = gl_mul(res[c], zhi);
 }
 
+// The light gates of a circuit in ONE launch: interpreted gates (Constant, PublicInput and whatever else has no native form) and
+// the native ArithmeticGate / BaseSumGate, evaluated one after the other by the same thread with a single update of `out`.  Alone
+// each of them is a latency-bound kernel of a few hundred to a few thousand instructions per point (one instruction per 5 - 8
+// cycles against 3.7 for the heavy gates); together their loads overlap and three read-modify-write passes over `out` go away.
+struct LightGates { u32 count; u32 g[8]; };
+template <bool CHECK>
+__global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_light(QuotientArgs a, LightGates L, u32 accumulate, unsigned long long *flag) {
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
+  const u64 i0 = (u64)blockIdx.x * T + tid;
+  if (!CHECK && i0 >= a.count) return;            // no barrier is used below
+  const u64 i = i0 < a.count ? i0 : a.count - 1;
+  u64 sum[QUOTIENT_MAX_CH];
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) sum[c] = 0;
+  for (u32 k = 0; k < L.count; k++) {
+    const u32 g = L.g[k];
+    const GateDev G = q_load_gate(a, g);
+    if (CHECK) {
+      const u64 sel = a.consts[(u64)G.selector_index * a.stride + i];
+      if (!__any(sel == G.selector_value)) continue;  // wave-uniform
+    }
+    u64 val[QUOTIENT_MAX_CH];
+    switch (a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0) {  // wave-uniform
+      case LCP2_GATE_NATIVE_ARITHMETIC: q_gate_value<LCP2_GATE_NATIVE_ARITHMETIC>(a, g, G, i, lds, T, tid, val); break;
+      case LCP2_GATE_NATIVE_BASE_SUM2: q_gate_value<LCP2_GATE_NATIVE_BASE_SUM2>(a, g, G, i, lds, T, tid, val); break;
+      default: q_gate_value<0>(a, g, G, i, lds, T, tid, val); break;
+    }
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < a.num_challenges) sum[c] = gl_add(sum[c], val[c]);
+  }
+  if (CHECK) {
+    // on a row of H only the row's own gate has a non-zero filter, so the sum is that gate's value
+    bool bad = false;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < a.num_challenges && sum[c] != 0) bad = true;
+    if (bad) atomicMin(flag, (unsigned long long)i + 1);
+  } else {
+    const u64 ig = a.leaf0 + i;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+      if (c < a.num_challenges) a.out[(u64)c * a.N + ig] = accumulate ? gl_add(a.out[(u64)c * a.N + ig], sum[c]) : sum[c];
+  }
+}
+
 // build()-time check of a native evaluator against the program it claims to be (random points in a.wires / a.consts)
 template <u32 NATIVE>
 __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_native_check(QuotientArgs a, u32 g, unsigned long long *flag) {
@@ -687,19 +734,46 @@ void launch_gate(hipStream_t s, const QuotientArgs &a, const GateDev &G, u32 g, 
 }
 }  // namespace
 
-// host_gates: the gate table as uploaded (staged code offsets); gates without constraints are skipped
-void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates) {
+namespace {
+// a gate that goes into the light-gate launch: no native form, or one of the two small native ones
+bool is_light(const QuotientArgs &a, const GateDev &G) {
+  const u32 k = a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0;
+  return k == 0 || k == LCP2_GATE_NATIVE_ARITHMETIC || k == LCP2_GATE_NATIVE_BASE_SUM2;
+}
+template <bool CHECK>
+u32 launch_gates(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
   u32 launched = 0;
+  LightGates L{};
+  auto flush = [&] {
+    if (!L.count) return;
+    const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
+    const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+    hipLaunchKernelGGL((k_q_light<CHECK>), grid, block, lds, s, a, L, launched ? 1u : 0u, flag);
+    launched++;
+    L.count = 0;
+  };
   for (u32 g = 0; g < host_gates.size(); g++) {
     if (host_gates[g].num_constraints == 0) continue;
-    launch_gate<false>(s, a, host_gates[g], g, launched ? 1u : 0u, nullptr);
+    if (is_light(a, host_gates[g])) {
+      L.g[L.count++] = g;
+      if (L.count == 8) flush();
+      continue;
+    }
+    launch_gate<CHECK>(s, a, host_gates[g], g, launched ? 1u : 0u, flag);
     launched++;
   }
+  flush();
+  return launched;
+}
+}  // namespace
+
+// host_gates: the gate table as uploaded (staged code offsets); gates without constraints are skipped
+void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates) {
+  const u32 launched = launch_gates<false>(s, a, host_gates, nullptr);
   hipLaunchKernelGGL(k_q_perm, dim3((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), dim3(QUOTIENT_THREADS), 0, s, a, launched ? 1u : 0u);
 }
 void launch_gate_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
-  for (u32 g = 0; g < host_gates.size(); g++)
-    if (host_gates[g].num_constraints) launch_gate<true>(s, a, host_gates[g], g, 0, flag);
+  launch_gates<true>(s, a, host_gates, flag);
 }
 void launch_native_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
   const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
