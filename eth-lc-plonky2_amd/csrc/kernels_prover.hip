@@ -651,6 +651,60 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_perm(QuotientArgs a, 
     if (c < CH) a.out[(u64)c * a.N + ig] = gl_mul(res[c], zhi);
 }
 
+// filter_g(point): the selector polynomial of gate g's group with the factor of g's own value left out
+__device__ __forceinline__ u64 q_filter(const QuotientArgs &a, const GateDev &G, u64 i) {
+  const u64 s = a.consts[(u64)G.selector_index * a.stride + i];
+  u64 f = 1;
+  for (u32 j = G.group_start; j < G.group_end; j++)
+    if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
+  if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
+  return f;
+}
+// ArithmeticGate and BaseSumGate<2> of one circuit in one walk over the wires (both read the routed wires from index 0 up: the
+// wires are loaded once, 16 at a time from the top, and feed both evaluators; same constraint order as q_arithmetic_native and
+// q_base_sum2_native, so the sums are the same field elements)
+__device__ __forceinline__ void q_arith_base_pair(const QuotientArgs &a, u64 i, const GateDev &GA, const GateDev &GB, u64 valA[QUOTIENT_MAX_CH], u64 valB[QUOTIENT_MAX_CH]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 CH = a.num_challenges;
+  QEmit eA, eB;
+  eA.CH = eB.CH = CH; eA.emitted = eB.emitted = 0;
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { eA.acc[c] = eB.acc[c] = 0; eA.step[c] = eB.step[c] = c < CH ? konst(a.alphas)[c] : 0; }
+  const int num_ops = (int)GA.num_constraints, num_limbs = (int)GB.num_constraints - 1;
+  const u64 *W = a.wires + i;
+  const u64 st = a.stride;
+  const u64 c0 = a.consts[(u64)a.num_selectors * st + i], c1 = a.consts[(u64)(a.num_selectors + 1) * st + i];
+  const int top_wire = max(4 * num_ops, num_limbs + 1), last_wire = (int)a.num_wires - 1;
+  u64 sum = 0, w0 = 0;
+  for (int hi = (top_wire + 15) & ~15; hi > 0; hi -= 16) {  // wires [hi - 16, hi)
+    u64 w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = W[(u64)min(hi - 16 + j, last_wire) * st];
+#pragma unroll
+    for (int kk = 3; kk >= 0; kk--) {
+      if ((hi - 16) / 4 + kk < num_ops) {
+        const u64 comp = gl_add(gl_mul(gl_mul(w[4 * kk], w[4 * kk + 1]), c0), gl_mul(w[4 * kk + 2], c1));
+        eA(gl_sub(w[4 * kk + 3], comp));
+      }
+    }
+#pragma unroll
+    for (int j = 15; j >= 0; j--) {
+      const int limb = hi - 16 + j - 1;  // wire 0 is the sum, limb l sits on wire l + 1
+      if (limb >= 0 && limb < num_limbs) {
+        eB(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        sum = gl_add(gl_add(sum, sum), w[j]);
+      }
+    }
+    if (hi == 16) w0 = w[0];
+  }
+  eB(gl_sub(sum, w0));
+  const u64 fA = q_filter(a, GA, i), fB = q_filter(a, GB, i);
+#pragma unroll
+  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+    if (c < CH) { valA[c] = gl_mul(fA, eA.acc[c]); valB[c] = gl_mul(fB, eB.acc[c]); }
+#endif
+}
+
 // The light gates of a circuit in ONE launch: interpreted gates (Constant, PublicInput and whatever else has no native form) and
 // the native ArithmeticGate / BaseSumGate, evaluated one after the other by the same thread with a single update of `out`.  Alone
 // each of them is a latency-bound kernel of a few hundred to a few thousand instructions per point (one instruction per 5 - 8
@@ -666,7 +720,32 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_light(QuotientArgs a,
   u64 sum[QUOTIENT_MAX_CH];
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) sum[c] = 0;
+  // an ArithmeticGate and a BaseSumGate in the list share one walk over the wires
+  u32 ka = ~0u, kb = ~0u;
+  if (a.use_native)
+    for (u32 k = 0; k < L.count; k++) {
+      const u32 kind = konst((const u32 *)a.gates)[(size_t)L.g[k] * (sizeof(GateDev) / 4) + 7] & LCP2_GATE_NATIVE_MASK;
+      if (kind == LCP2_GATE_NATIVE_ARITHMETIC && ka == ~0u) ka = k;
+      if (kind == LCP2_GATE_NATIVE_BASE_SUM2 && kb == ~0u) kb = k;
+    }
+  const bool pair = ka != ~0u && kb != ~0u;
+  if (pair) {
+    const GateDev GA = q_load_gate(a, L.g[ka]), GB = q_load_gate(a, L.g[kb]);
+    bool run = true;
+    if (CHECK) {
+      const u64 sa = a.consts[(u64)GA.selector_index * a.stride + i], sb = a.consts[(u64)GB.selector_index * a.stride + i];
+      run = __any(sa == GA.selector_value || sb == GB.selector_value);
+    }
+    if (run) {
+      u64 va[QUOTIENT_MAX_CH], vb[QUOTIENT_MAX_CH];
+      q_arith_base_pair(a, i, GA, GB, va, vb);
+#pragma unroll
+      for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+        if (c < a.num_challenges) sum[c] = gl_add(va[c], vb[c]);
+    }
+  }
   for (u32 k = 0; k < L.count; k++) {
+    if (pair && (k == ka || k == kb)) continue;
     const u32 g = L.g[k];
     const GateDev G = q_load_gate(a, g);
     if (CHECK) {
