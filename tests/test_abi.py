@@ -46,3 +46,43 @@ def test_no_cpu_fallback_without_device():
         m.Context(0)
     assert e.value.status == -2
     assert lib.lcp2_status_str(-5) == b"witness does not satisfy the circuit"
+
+
+def test_proof_layout_is_consistent_and_refuses_bad_parameters():
+    """lcp2_proof_layout_of: the offsets tile the proof without gaps, agree with lcp2_proof_words, and bad parameters are refused"""
+    import eth_lc_plonky2_amd as m
+    lib = m.load_library()
+    for db in (5, 12, 19, 22):
+        p = m.standard_params(db, 4)
+        L = m.proof_layout(p)
+        capw = 4 << p.cap_height
+        assert L.total == lib.lcp2_proof_words(ctypes.byref(p)) and L.cap_words == capw
+        assert (L.wires_cap, L.zs_cap, L.quot_cap, L.op_constants) == (0, capw, 2 * capw, 3 * capw)
+        npp = (p.num_routed_wires + p.quotient_degree_factor - 1) // p.quotient_degree_factor - 1
+        ch = p.num_challenges
+        assert L.op_sigmas == L.op_constants + 2 * p.num_constants and L.op_wires == L.op_sigmas + 2 * p.num_routed_wires
+        assert L.op_zs == L.op_wires + 2 * p.num_wires and L.op_zs_next == L.op_zs + 2 * ch
+        assert L.op_partial_products == L.op_zs_next + 2 * ch and L.op_quotient == L.op_partial_products + 2 * ch * npp
+        assert L.fri_caps == L.op_quotient + 2 * ch * p.quotient_degree_factor and L.queries == L.fri_caps + p.num_fri_layers * capw
+        # one query round: four initial-tree openings, then the FRI layers
+        lg = p.degree_bits + p.rate_bits
+        pos = 0
+        for o, cols in enumerate((p.num_constants + p.num_routed_wires, p.num_wires, ch * (1 + npp), ch * p.quotient_degree_factor)):
+            assert (L.q_init_off[o], L.q_init_cols[o]) == (pos, cols)
+            pos += cols + 4 * (lg - p.cap_height)
+        assert L.q_init_sib == lg - p.cap_height
+        for l in range(p.num_fri_layers):
+            lg -= p.fri_arity_bits[l]
+            assert (L.q_step_off[l], L.q_step_sib[l]) == (pos, lg - p.cap_height)
+            pos += (2 << p.fri_arity_bits[l]) + 4 * (lg - p.cap_height)
+        assert L.query_words == pos and L.final_poly == L.queries + p.num_query_rounds * pos
+        assert L.pow_witness == L.final_poly + 2 * L.final_len and L.total == L.pow_witness + 1
+    bad = m.standard_params(10, 4)
+    bad.quotient_degree_factor = 0
+    with pytest.raises(m.Lcp2Error):
+        m.proof_layout(bad)
+    bad = m.standard_params(10, 4)
+    bad.cap_height = 40
+    with pytest.raises(m.Lcp2Error):
+        m.proof_layout(bad)
+    assert lib.lcp2_proof_layout_of(None, None) != 0
