@@ -187,6 +187,46 @@ def test_plonky2_gate_programs_hold_on_their_witness_rows(oracle):
     oc.close()
 
 
+def test_recursion_gate_programs(oracle):
+    """plonky2's ArithmeticExtensionGate, MulExtensionGate, ReducingGate, RandomAccessGate and ExponentiationGate as programs
+    (recursion_gates.py): constraint counts as plonky2's num_constraints(), zero on rows filled by the matching generators,
+    non-zero when a wire the gate constrains is changed, and a circuit made of them proves (oracle) and verifies (product)."""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import recursion_gates as rg
+    params = m.standard_params(6, 4)
+    circ, wires, pis = rg.recursion_gates_circuit(params, seed=5)
+    gs = circ.gateset
+    assert gs.names == ["NoopGate", "ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate", "ExponentiationGate", "RandomAccessGate"]
+    assert [g.num_constraints for g in gs.gates] == [0, 2 * 43, 2 * 10, 2 * 13, 66 + 1, 4 * (4 + 2) + 2] and gs.num_selectors == 2
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    assert oc.check_witness(wires, pis)[0] == 0
+    # rows 0..4 hold one gate of each kind in the order Reducing, ArithmeticExtension, MulExtension, Exponentiation, RandomAccess;
+    # per kind: a wire whose change must break the row
+    routed_ra = (2 + 16) * 4 + 2
+    for row, wire in ((0, 3), (0, 6 + 42), (0, 6 + 43 + 5), (1, 0), (1, 77), (2, 4), (2, 6 * 12 + 5), (3, 0), (3, 1 + 65), (3, 67), (3, 2 + 66 + 30),
+                      (4, 0), (4, 1), (4, 18 + 1), (4, routed_ra + 2), (4, 72)):
+        w2 = wires.copy()
+        w2[wire, row] = np.uint64((int(w2[wire, row]) + 1) % m.GOLDILOCKS_P)
+        bad, first = oc.check_witness(w2, pis)
+        assert bad > 0 and first[0] == row, (row, wire)
+    # an unselected list item of a RandomAccessGate row is free
+    idx = int(wires[0, 4])
+    w2 = wires.copy()
+    w2[2 + (idx + 1) % 16, 4] ^= np.uint64(5)
+    assert oc.check_witness(w2, pis)[0] == 0
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof, pis) == 0
+    digest, cap = oc.digest()
+    vd = m.CircuitData.verifier_only(circ, digest, cap)
+    vd.verify(proof, pis)
+    bad = proof.copy()
+    bad[3 * 64 + 9] ^= np.uint64(1)  # an opening
+    with pytest.raises(m.ProofRejected):
+        vd.verify(bad, pis)
+    oc.close()
+    vd.close()
+
+
 def test_proof_byte_serialisation_round_trip(oracle):
     """ProofWithPublicInputs <-> bytes (plonky2 util/serialization.rs layout, PARITY UNPINNED: the reference holds no serialised
     proof).  Round trip, exact size, u8 sibling counts where the layout says, and every malformed buffer is refused."""
