@@ -1,5 +1,6 @@
 """More of plonky2's gate library as constraint programs: the gates its recursion circuits are built from
-(plonky2 0.1.4 gates/arithmetic_extension.rs, multiplication_extension.rs, reducing.rs, random_access.rs, exponentiation.rs;
+(plonky2 0.1.4 gates/arithmetic_extension.rs, multiplication_extension.rs, reducing.rs, reducing_extension.rs, random_access.rs,
+exponentiation.rs, poseidon_mds.rs;
 [RECALL] of the published source: wire layouts and the order of eval_unfiltered, D = 2, standard_recursion_config).  They run
 through the interpreter of K6 (no native evaluator is claimed) and through the host verifier like any other program; the
 recursive verifier of this repository (host/recursion.cpp) does not need them - it is made of ArithmeticGate operations - they
@@ -11,7 +12,7 @@ vanishes on a valid row and does not on a perturbed one, and by `recursion_gates
 import numpy as np
 
 from . import gl_np as gl
-from .circuit import (GATE_EMIT_FORWARD, Circuit, GateSet, W, C, gate_noop, sigma_values)
+from .circuit import (GATE_EMIT_FORWARD, K_REG, Circuit, GateSet, W, C, gate_noop, sigma_values)
 
 P = gl.P
 EXT_W = 7  # F[X] / (X^2 - 7)
@@ -21,6 +22,9 @@ MUL_EXT_OPS = 13         # num_routed_wires / (3 D)
 REDUCING_COEFFS = 43     # min(num_routed - 3 D, (num_wires - 2 D) / (D + 1))
 RANDOM_ACCESS_BITS, RANDOM_ACCESS_COPIES, RANDOM_ACCESS_EXTRA = 4, 4, 2
 EXP_POWER_BITS = 66      # min(num_routed - 3, (num_wires - 2) / 2)
+REDUCING_EXT_COEFFS = 32 # min((num_routed - 3 D) / D, (num_wires - 2 D) / (2 D))
+MDS_CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+MDS_DIAG = [8] + [0] * 11
 
 
 # ---------------------------------------------------------------- extension arithmetic inside a program
@@ -96,6 +100,39 @@ def gate_reducing(asm):
         prev = accs[i]
 
 
+def gate_reducing_extension(asm):
+    """ReducingExtensionGate<2> { num_coeffs: 32 }: as ReducingGate with extension-field coefficients (2 wires each)"""
+    asm.flags |= GATE_EMIT_FORWARD
+    out, alpha, prev = (W(0), W(1)), (W(2), W(3)), (W(4), W(5))
+    start = 6 + 2 * REDUCING_EXT_COEFFS
+    for i in range(REDUCING_EXT_COEFFS):
+        t = _ext_mul(asm, prev, alpha)
+        for k in range(2):
+            asm.add(t[k], W(6 + 2 * i + k), dst=t[k][1])
+        acc = (W(start + 2 * i), W(start + 2 * i + 1)) if i < REDUCING_EXT_COEFFS - 1 else out
+        _emit_ext_diff(asm, acc, t)
+        asm.release(*t)
+        prev = acc
+
+
+def gate_poseidon_mds(asm):
+    """PoseidonMdsGate: 12 extension inputs (wires 2i, 2i+1), 12 extension outputs (wires 24 + 2i, 25 + 2i); constraints
+    output - MDS(input).  The MDS layer is base-field linear, so it acts on each component: the PMDS instruction with zero
+    constants on the components' register window; the constraints are listed output by output, as plonky2 lists them."""
+    asm.flags |= GATE_EMIT_FORWARD
+    asm.reserve(0, 48)
+    zero = asm.imm(0)
+    for k in range(2):
+        for i in range(12):
+            asm.add(W(2 * i + k), zero, dst=i)
+        asm.pmds(12, 0, [0] * 12)
+        for i in range(12):
+            asm.sub(W(24 + 2 * i + k), (K_REG, 12 + i), dst=24 + 12 * k + i)
+    for i in range(12):
+        asm.emit((K_REG, 24 + i))
+        asm.emit((K_REG, 36 + i))
+
+
 def gate_random_access(asm):
     """RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 }: per copy access_index, claimed_element and 16 list items
     (routed), then the 2 extra constants (routed), then 4 bit wires per copy.  Constraints per copy: the bits are boolean, they
@@ -164,6 +201,8 @@ def recursion_gateset():
     """sorted by (degree, name) as plonky2 sorts a gate set; two selector groups under max_degree 9"""
     return GateSet([
         ("NoopGate", 0, gate_noop),
+        ("PoseidonMdsGate", 1, gate_poseidon_mds),
+        ("ReducingExtensionGate", 2, gate_reducing_extension),
         ("ReducingGate", 2, gate_reducing),
         ("ArithmeticExtensionGate", 3, gate_arithmetic_extension),
         ("MulExtensionGate", 3, gate_mul_extension),
@@ -208,6 +247,29 @@ def row_reducing(rng, num_wires=135):
     return w
 
 
+def row_reducing_extension(rng, num_wires=135):
+    w = [int(v) for v in rng.integers(0, P, size=num_wires, dtype=np.uint64)]
+    alpha, acc = (w[2], w[3]), (w[4], w[5])
+    start = 6 + 2 * REDUCING_EXT_COEFFS
+    for i in range(REDUCING_EXT_COEFFS):
+        t = _emul(acc, alpha)
+        acc = ((t[0] + w[6 + 2 * i]) % P, (t[1] + w[7 + 2 * i]) % P)
+        if i < REDUCING_EXT_COEFFS - 1:
+            w[start + 2 * i], w[start + 2 * i + 1] = acc
+        else:
+            w[0], w[1] = acc
+    return w
+
+
+def row_poseidon_mds(rng, num_wires=135):
+    w = [int(v) for v in rng.integers(0, P, size=num_wires, dtype=np.uint64)]
+    for k in range(2):
+        s = [w[2 * i + k] for i in range(12)]
+        for r in range(12):
+            w[24 + 2 * r + k] = (sum(s[(i + r) % 12] * MDS_CIRC[i] for i in range(12)) + s[r] * MDS_DIAG[r]) % P
+    return w
+
+
 def row_random_access(rng, c0, c1, num_wires=135):
     w = [int(v) for v in rng.integers(0, P, size=num_wires, dtype=np.uint64)]
     vec = 1 << RANDOM_ACCESS_BITS
@@ -241,13 +303,14 @@ def row_exponentiation(rng, num_wires=135):
 
 
 def recursion_gates_circuit(params, seed):
-    """A provable circuit whose rows cycle through the five gates (no copy constraints: identity permutation, no public inputs).
+    """A provable circuit whose rows cycle through the seven gates (no copy constraints: identity permutation, no public inputs).
     Returns (Circuit, wires [num_wires][n], public_inputs = [])."""
     rng = np.random.default_rng(seed)
     gs = recursion_gateset()
     n, Wn, NR = 1 << params.degree_bits, params.num_wires, params.num_routed_wires
     assert params.num_constants == gs.num_selectors + 2 and Wn >= 135 and NR >= 80
-    kinds = ["ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate", "ExponentiationGate", "RandomAccessGate"]
+    kinds = ["ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate", "ExponentiationGate", "RandomAccessGate", "ReducingExtensionGate",
+             "PoseidonMdsGate"]
     gate_of_row = np.zeros(n, dtype=np.int64)  # NoopGate
     wires = np.zeros((Wn, n), dtype=np.uint64)
     c0 = rng.integers(0, P, size=n, dtype=np.uint64)
@@ -256,7 +319,8 @@ def recursion_gates_circuit(params, seed):
         kind = kinds[r % len(kinds)]
         gate_of_row[r] = gs.index(kind)
         a, b = int(c0[r]), int(c1[r])
-        row = {"ReducingGate": lambda: row_reducing(rng, Wn), "ArithmeticExtensionGate": lambda: row_arithmetic_extension(rng, a, b, Wn),
+        row = {"ReducingExtensionGate": lambda: row_reducing_extension(rng, Wn), "PoseidonMdsGate": lambda: row_poseidon_mds(rng, Wn),
+               "ReducingGate": lambda: row_reducing(rng, Wn), "ArithmeticExtensionGate": lambda: row_arithmetic_extension(rng, a, b, Wn),
                "MulExtensionGate": lambda: row_mul_extension(rng, a, Wn), "ExponentiationGate": lambda: row_exponentiation(rng, Wn),
                "RandomAccessGate": lambda: row_random_access(rng, a, b, Wn)}[kind]()
         wires[:, r] = np.array(row, dtype=np.uint64)

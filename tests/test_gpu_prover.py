@@ -376,8 +376,8 @@ def test_nonstandard_params_equal_oracle(gpu_ctx, oracle, name, degree_bits, kw)
 
 @pytest.mark.parametrize("degree_bits", [5, 8, 11])
 def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
-    """a circuit of plonky2's recursion gates (recursion_gates.py: extension arithmetic, ReducingGate, RandomAccessGate,
-    ExponentiationGate, all interpreted by K6): the GPU proof equals the oracle's word for word and verifies"""
+    """a circuit of plonky2's recursion gates (recursion_gates.py: extension arithmetic, the reducing gates, RandomAccessGate,
+    ExponentiationGate, PoseidonMdsGate, all interpreted by K6): the GPU proof equals the oracle's word for word and verifies"""
     import eth_lc_plonky2_amd as m
     from eth_lc_plonky2_amd import recursion_gates as rg
     params = m.standard_params(degree_bits, 4)
@@ -389,7 +389,7 @@ def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
     assert _first_mismatch(m, params, got, want) is None, _first_mismatch(m, params, got, want)
     data.verify(got, pis)
     w2 = wires.copy()
-    w2[67, 3] ^= np.uint64(1)  # the output of an ExponentiationGate row
+    w2[67, 3] ^= np.uint64(1)  # the output of the ExponentiationGate on row 3
     with pytest.raises(m.Lcp2Error) as e:
         data.prove(w2, pis)
     assert e.value.status == -5  # LCP2_E_UNSAT

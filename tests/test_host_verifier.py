@@ -188,23 +188,25 @@ def test_plonky2_gate_programs_hold_on_their_witness_rows(oracle):
 
 
 def test_recursion_gate_programs(oracle):
-    """plonky2's ArithmeticExtensionGate, MulExtensionGate, ReducingGate, RandomAccessGate and ExponentiationGate as programs
-    (recursion_gates.py): constraint counts as plonky2's num_constraints(), zero on rows filled by the matching generators,
-    non-zero when a wire the gate constrains is changed, and a circuit made of them proves (oracle) and verifies (product)."""
+    """plonky2's ArithmeticExtensionGate, MulExtensionGate, ReducingGate, ReducingExtensionGate, RandomAccessGate, ExponentiationGate
+    and PoseidonMdsGate as programs (recursion_gates.py): constraint counts as plonky2's num_constraints(), zero on rows filled by
+    the matching generators, non-zero when a wire the gate constrains is changed, and a circuit made of them proves (oracle) and
+    verifies (product)."""
     import eth_lc_plonky2_amd as m
     from eth_lc_plonky2_amd import recursion_gates as rg
     params = m.standard_params(6, 4)
     circ, wires, pis = rg.recursion_gates_circuit(params, seed=5)
     gs = circ.gateset
-    assert gs.names == ["NoopGate", "ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate", "ExponentiationGate", "RandomAccessGate"]
-    assert [g.num_constraints for g in gs.gates] == [0, 2 * 43, 2 * 10, 2 * 13, 66 + 1, 4 * (4 + 2) + 2] and gs.num_selectors == 2
+    assert gs.names == ["NoopGate", "PoseidonMdsGate", "ReducingExtensionGate", "ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate",
+                        "ExponentiationGate", "RandomAccessGate"]
+    assert [g.num_constraints for g in gs.gates] == [0, 2 * 12, 2 * 32, 2 * 43, 2 * 10, 2 * 13, 66 + 1, 4 * (4 + 2) + 2] and gs.num_selectors == 2
     oc = oracle_lib.OracleCircuit(oracle, circ)
     assert oc.check_witness(wires, pis)[0] == 0
-    # rows 0..4 hold one gate of each kind in the order Reducing, ArithmeticExtension, MulExtension, Exponentiation, RandomAccess;
-    # per kind: a wire whose change must break the row
+    # rows 0..6 hold one gate of each kind in the order Reducing, ArithmeticExtension, MulExtension, Exponentiation, RandomAccess,
+    # ReducingExtension, PoseidonMds; per kind: wires whose change must break the row
     routed_ra = (2 + 16) * 4 + 2
     for row, wire in ((0, 3), (0, 6 + 42), (0, 6 + 43 + 5), (1, 0), (1, 77), (2, 4), (2, 6 * 12 + 5), (3, 0), (3, 1 + 65), (3, 67), (3, 2 + 66 + 30),
-                      (4, 0), (4, 1), (4, 18 + 1), (4, routed_ra + 2), (4, 72)):
+                      (4, 0), (4, 1), (4, 18 + 1), (4, routed_ra + 2), (4, 72), (5, 2), (5, 6 + 2 * 31 + 1), (5, 6 + 64 + 9), (6, 5), (6, 24 + 23)):
         w2 = wires.copy()
         w2[wire, row] = np.uint64((int(w2[wire, row]) + 1) % m.GOLDILOCKS_P)
         bad, first = oc.check_witness(w2, pis)
