@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void k_perm_chunks(PermArgs a) {
       for (u32 j = k * a.chunk; j < a.num_routed && j < (k + 1) * a.chunk; j++) {
         u64 w = gl_canon(a.wires[(u64)j * a.n + row]);
         u64 wg = gl_add(w, gamma);
-        pn[k] = gl_mul(pn[k], gl_add(wg, gl_mul(bx, a.k_is[j])));
-        pd[k] = gl_mul(pd[k], gl_add(wg, gl_mul(beta, a.sigmas[(u64)j * a.n + row])));
+        // lazy through the products (any u64 congruent to the element); the batch inversion below multiplies canonically
+        pn[k] = gl_mul_nc(pn[k], gl_add_nc(gl_mul_nc(bx, a.k_is[j]), wg));
+        pd[k] = gl_mul_nc(pd[k], gl_add_nc(gl_mul_nc(beta, a.sigmas[(u64)j * a.n + row]), wg));
       }
     }
   }
@@ -610,9 +611,11 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_perm(QuotientArgs a, 
 #pragma unroll
           for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
             if (c < CH) {
+              // lazy values (any u64 congruent to the element) through the products: gl_mul_nc takes them, and the chunk
+              // products only meet canonical arithmetic in the gl_mul of the term below
               const u64 wg = gl_add(w[jj], gamma[c]);
-              pn[c] = gl_mul(pn[c], gl_add(wg, gl_mul(bx[c], kj)));
-              pd[c] = gl_mul(pd[c], gl_add(wg, gl_mul(beta[c], sg[jj])));
+              pn[c] = gl_mul_nc(pn[c], gl_add_nc(gl_mul_nc(bx[c], kj), wg));
+              pd[c] = gl_mul_nc(pd[c], gl_add_nc(gl_mul_nc(beta[c], sg[jj]), wg));
             }
         }
       }
