@@ -880,14 +880,18 @@ __global__ __launch_bounds__(256) void k_eval_polys(EvalArgs a) {
   __shared__ u64 sh0[256], sh1[256];
   const u32 t = threadIdx.x, chunk = blockIdx.x, poly = blockIdx.y;
   const u64 *c = a.coeffs + (u64)poly * a.col_stride + (u64)chunk * a.chunk_len;
+  // Horner in lazy arithmetic: acc = acc * z^256 + c with acc any u64 pair congruent to the value (gl_mul_nc takes it), one
+  // canonical product per component so that gl_add_nc has its canonical operand, and 7 z_1 hoisted out of the loop
   gl2 acc = gl2_make(0, 0);
-  const gl2 z256 = gl2_make(a.zstep[0], a.zstep[1]);
+  const u64 z0 = a.zstep[0], z1 = a.zstep[1], z1w = gl_mul(GL_W, z1);
   for (int m = (int)a.items - 1; m >= 0; m--) {
     u32 idx = t + 256u * (u32)m;
-    acc = gl2_mul(acc, z256);
-    if (idx < a.chunk_len) acc = gl2_add_base(acc, c[idx]);
+    const u64 coeff = idx < a.chunk_len ? c[idx] : 0;  // canonical: the coefficient buffers are the library's own
+    const u64 n0 = gl_add_nc(gl_add_nc(gl_mul_nc(acc.c0, z0), gl_mul(acc.c1, z1w)), coeff);
+    const u64 n1 = gl_add_nc(gl_mul_nc(acc.c0, z1), gl_mul(acc.c1, z0));
+    acc = gl2_make(n0, n1);
   }
-  acc = gl2_mul(acc, gl2_make(a.zpow_t[2 * t], a.zpow_t[2 * t + 1]));
+  acc = gl2_mul(gl2_make(gl_canon(acc.c0), gl_canon(acc.c1)), gl2_make(a.zpow_t[2 * t], a.zpow_t[2 * t + 1]));
   sh0[t] = acc.c0; sh1[t] = acc.c1;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
