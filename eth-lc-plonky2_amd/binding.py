@@ -223,7 +223,9 @@ class Oracle:
 
 
 class Context:
-    """One prover context = one GPU + one HIP stream (lcp2_ctx)."""
+    """One prover context = one GPU + one HIP stream (lcp2_ctx).  stream: a raw hipStream_t, or None / 0 for a private
+    non-blocking stream - torch.cuda.current_stream().cuda_stream is 0 for the default stream, so work queued there (a fill, an
+    upload) is NOT ordered before the library's kernels: torch.cuda.synchronize() first, ctx.sync() before reading results."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load_library()

@@ -2,6 +2,7 @@
 // decomposition.  One workgroup = one 2^L-element slab in LDS (up to 68 KiB with padding, so two
 // workgroups share a CU's 160 KiB), NTT_THREADS threads, one barrier per register step (3-4 stages).
 // Global traffic is one read and one write of the slab per pass, in runs of >= 128 bytes.
+#include <cstdlib>
 #include "internal.hpp"
 
 namespace lcp2 {
@@ -125,7 +126,8 @@ void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wg
   const bool direct = inverse ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT);
   // (forward passes only: the inverse instantiations need 30-odd more VGPRs than the 128 of four waves per SIMD and lose to the
   // plain kernel once they spill)
-  if (!inverse && (strided || contiguous) && (!factor || (direct && strided)) && total < (1ull << 31)) {
+  static const int pf_mask = getenv("LCP2_NTT_PF") ? atoi(getenv("LCP2_NTT_PF")) : 3;  // debugging aid: bit 0 strided, bit 1 contiguous form
+  if (!inverse && ((strided && (pf_mask & 1)) || (contiguous && (pf_mask & 2))) && (!factor || (direct && strided)) && total < (1ull << 31)) {
     // slabs per workgroup: only the first load of a workgroup is exposed, so as many as still leave 2048 workgroups (4 rounds
     // of the 512 resident ones) and divide the slab count into a multiple of 8 workgroups (the XCD mapping)
     u32 spw = 0;

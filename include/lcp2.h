@@ -83,8 +83,11 @@ const char *lcp2_status_str(int status);
 int lcp2_abi_version(void);
 int lcp2_device_count(void);
 
-/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. the caller's
- * current stream) or NULL for a private stream. */
+/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. the caller's current stream) or NULL for a private,
+ * NON-BLOCKING stream.  The legacy default stream has the handle NULL and therefore cannot be named: a caller that works on
+ * it (PyTorch's default stream is stream 0) gets the private stream, which does not order itself against the default stream -
+ * synchronise the producer of a device buffer before handing it over, and lcp2_ctx_sync before consuming results elsewhere.
+ * Every entry point that returns host data has synchronised the context's stream when it returns. */
 int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out);
 void lcp2_ctx_destroy(lcp2_ctx *ctx);
 int lcp2_ctx_sync(lcp2_ctx *ctx);
