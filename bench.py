@@ -126,6 +126,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     import numpy as np
     import torch
     comm = m.parallel.TorchComm(dist, dev, ctx)
+    form = comm.self_check()  # known-answer all-gather on a library buffer: "in-place", or "staged" if the aliased form misbehaves
     prover = m.parallel.ShardedProver(ctx, circ, rank, world, comm, constants_sigmas_ptr=cs_ptr, mem=m.MEM_DEVICE)
     prover.finish_build()
     n = 1 << circ.params.degree_bits
@@ -135,6 +136,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     for it in range(reps + 1):
         torch.cuda.synchronize()
         dist.barrier()
+        comm.bytes_gathered = 0
         t0 = time.perf_counter()
         proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True)
         torch.cuda.synchronize()
@@ -151,8 +153,8 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     prover.close()
     n_words = 1 << (circ.params.degree_bits + circ.params.rate_bits)
     return {"workload": "configs[3]: the same n=2^%d proof sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
-            "ms_per_proof": float(tt.item()) * 1e3, "world": world, "proof_verified": ok,
-            "exchange_bytes_received_per_rank": int(8 * (world - 1) / world * (2 * circ.params.num_wires * n + circ.params.num_challenges * n_words)),
+            "ms_per_proof": float(tt.item()) * 1e3, "world": world, "rccl_world_size": dist.get_world_size(), "proof_verified": ok,
+            "all_gather_form": form, "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
             "exchange": "RCCL all_gather_into_tensor (in place): witness values, witness coefficients, %d quotient planes; all_reduce(SUM) of 3 caps and the proof array" % circ.params.num_challenges}
 
 
@@ -167,7 +169,80 @@ def parse():
                     "(RCCL process group of size 1: exercises the N > 1 code path on a one-GPU box)")
     ap.add_argument("--cpu-sample-bits", type=int, default=18, help="log2 rows of the oracle's bounded sample")
     ap.add_argument("--no-real-gadgets", action="store_true", help="skip the examples/lc_prover side measurements")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof measurement (configs[3]) after the replica run")
+    ap.add_argument("--launch-dry-run", action="store_true", help="start the rank processes, let each report the environment it was "
+                    "given and exit before anything touches torch or the GPU (CPU test of the launcher)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(a):
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment: this process is only the launcher.  It starts N rank
+    processes of this same script (plain child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set: what
+    torch.distributed.run would have set), waits for them and relays rank 0's JSON line.  It never imports torch and never makes
+    a HIP call (a process that has initialised the GPU must not exec or be replaced; children are started, not exec'ed into).
+    A rank that fails ends the run with its exit code: the others are given a moment to fall out of their collectives, then
+    terminated by PID."""
+    import subprocess
+    assert "torch" not in sys.modules
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    args = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LCP2_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+        # rank 0 (and, in a dry run, every rank) writes its line into a pipe; the other ranks' stdout joins stderr
+        out = subprocess.PIPE if (r == 0 or a.launch_dry_run) else sys.stderr
+        procs.append(subprocess.Popen(args, env=env, stdout=out))
+    import threading
+    captured = {}
+
+    def drain(r, pipe):  # a pipe nobody reads would block its writer once the buffer is full
+        captured[r] = pipe.read().decode()
+
+    readers = [threading.Thread(target=drain, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs) if p.stdout is not None]
+    for t in readers:
+        t.start()
+    rc, failed_at, terminated = 0, None, False
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc, failed_at = code, time.monotonic()
+                print("bench.py launcher: rank %d exited with code %d" % (r, code), file=sys.stderr)
+        if failed_at is not None and live and not terminated and time.monotonic() - failed_at > 30.0:
+            for r in live:
+                procs[r].terminate()  # the exact PIDs this launcher started
+            terminated = True
+        if live:
+            time.sleep(0.2)
+    for t in readers:
+        t.join()
+    lines = [ln for r in sorted(captured) for ln in captured[r].splitlines() if ln.strip()]
+    if a.launch_dry_run:
+        kids = [json.loads(ln) for ln in lines]
+        print(json.dumps({"launch_dry_run": True, "gpus": a.gpus, "parent_imported_torch": "torch" in sys.modules,
+                          "children": sorted(kids, key=lambda k: k["rank"])}))
+    else:
+        for ln in lines:
+            print(ln)
+        if not lines and rc == 0:
+            rc = 4  # rank 0 printed nothing
+    sys.stdout.flush()
+    return rc
 
 
 def cpu_baseline(sample_bits, degree_bits):
@@ -201,6 +276,15 @@ def cpu_baseline(sample_bits, degree_bits):
 
 def main():
     a = parse()
+    if a.launch_dry_run and "WORLD_SIZE" in os.environ:  # a child of the dry run: report and leave, nothing imported
+        print(json.dumps({k.lower(): os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                         | {"rank": int(os.environ["RANK"]), "gpus_flag": a.gpus, "imported_torch": "torch" in sys.modules}))
+        return 0
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch_dry_run):
+        return launch(a)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s in the environment: the launcher's world size wins" % (a.gpus, os.environ["WORLD_SIZE"]),
+              file=sys.stderr)
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner when its first communicator comes
     # up) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes out through a
     # saved duplicate of the real stdout
@@ -274,14 +358,18 @@ def main():
     prof_all = ctx.prof_get()
     prof = {k: {f: prof_all[k][f] - prof0[k][f] for f in ("ms", "launches", "bytes")} for k in prof_all}
     data.verify(proof, pis)  # raises if the GPU proof is not accepted
-    sharded = None
-    if (world > 1 or a.force_sharded) and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
+    sharded, rc = None, 0
+    rccl_world = dist.get_world_size() if (world > 1 or a.force_sharded) else 1  # as the RCCL process group reports it
+    if (world > 1 or a.force_sharded) and not a.no_sharded and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
         data.close()  # the replica's 92 GB workspace makes room for the sharded handle
         torch.cuda.empty_cache()
         try:
             sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
-        except Exception as e:  # a side measurement must never take the bench line down
+        except Exception as e:  # the replica line still goes out, but the run fails: configs[3] is a first-class result for N > 1
+            import traceback
+            traceback.print_exc()
             sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+            rc = 3
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
@@ -306,7 +394,8 @@ def main():
             "config": {"workload": "configs[2]: full light-client-sized proof, n=2^%d rows x 135 wires, standard_recursion_config, "
                                    "synthetic satisfiable circuit over plonky2's own gate set (Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon; public inputs hashed in-circuit), recursive BLS verifier stubbed" % a.degree_bits,
                        "degree_bits": a.degree_bits, "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
-                       "parallelism": "replicas x%d (one independent proof per GPU)" % world},
+                       "parallelism": "replicas x%d (one independent proof per GPU)" % world,
+                       "rccl_world_size": rccl_world, "replica_proofs_per_hour": value},
             "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves", lh["bytes"] / max(lh["launches"], 1)),
                          "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
@@ -333,8 +422,12 @@ def main():
                 out["config"]["real_gadget_circuit_2p22"] = big
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or a.force_sharded:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # after a failed collective the group may not shut down cleanly; the exit code already says so
+            rc = rc or 3
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

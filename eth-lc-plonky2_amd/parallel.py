@@ -242,10 +242,19 @@ class _DevicePtr:
 
 
 class TorchComm:
-    """torch.distributed collectives for ShardedProver: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" on CPU."""
+    """torch.distributed collectives for ShardedProver: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" on CPU.
 
-    def __init__(self, dist, device=None, ctx=None):
+    The all-gather runs IN PLACE on the library's own buffer (a zero-copy tensor view of it) so that every byte crosses the
+    fabric once.  `LCP2_SHARDED_STAGED=1` (or `staged=True`) selects the conservative form instead: the rank's part is cloned
+    into a torch tensor, gathered into a torch-owned buffer and copied back.  `self_check()` runs a small in-place gather with
+    known contents first and falls back to the staged form if the result is not what every rank wrote - the in-place form over
+    RCCL with more than one rank has not run on hardware yet."""
+
+    def __init__(self, dist, device=None, ctx=None, staged=None):
+        import os
         self.dist, self.device, self.ctx = dist, device, ctx
+        self.staged = bool(int(os.environ.get("LCP2_SHARDED_STAGED", "0"))) if staged is None else bool(staged)
+        self.bytes_gathered = 0  # received by this rank through all_gather_device (exchange accounting of the bench)
 
     def sum_host(self, arr):
         import torch
@@ -256,18 +265,51 @@ class TorchComm:
         return t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
 
     def all_gather_tensor(self, out, rank):
-        """in-place all-gather on a 1-D tensor: rank r's part is out[r * k : (r + 1) * k] (RCCL recognises the aliasing and
-        moves every byte once; gloo gets a private copy of the input)"""
+        """all-gather on a 1-D tensor whose part r is out[r * k : (r + 1) * k].  In place over RCCL (it recognises the aliasing
+        and moves every byte once); gloo and the staged form get a private copy of the input."""
         k = out.numel() // self.dist.get_world_size()
         mine = out[rank * k:(rank + 1) * k]
+        if self.staged:
+            import torch
+            tmp = torch.empty_like(out)
+            self.dist.all_gather_into_tensor(tmp, mine.clone())
+            out.copy_(tmp)
+            return
         if self.dist.get_backend() != "nccl":
             mine = mine.clone()
         self.dist.all_gather_into_tensor(out, mine)
 
     def all_gather_device(self, ptr, total_words, words_per_rank):
         import torch
-        assert total_words == words_per_rank * self.dist.get_world_size()
+        world = self.dist.get_world_size()
+        assert total_words == words_per_rank * world
         self.ctx.sync()  # the library's stream has written this rank's part
         out = torch.as_tensor(_DevicePtr(ptr, total_words), device=self.device)  # aliases the library's buffer: no staging copies
         self.all_gather_tensor(out, self.dist.get_rank())
         torch.cuda.synchronize(self.device)
+        self.bytes_gathered += 8 * words_per_rank * (world - 1)
+
+    def self_check(self, words_per_rank=1 << 16):
+        """Known-answer all-gather on a library buffer.  Returns "in-place" or "staged" (the form that will be used), raises if
+        neither reproduces what the ranks wrote."""
+        world, rank = self.dist.get_world_size(), self.dist.get_rank()
+        buf = self.ctx.buffer_alloc(world * words_per_rank)
+        want = np.concatenate([(np.arange(words_per_rank, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(r + 1)) for r in range(world)])
+        try:
+            for attempt in range(2):
+                self.ctx.buffer_write(buf, np.zeros(world * words_per_rank, dtype=np.uint64))
+                self.ctx.buffer_write(buf + 8 * rank * words_per_rank, want[rank * words_per_rank:(rank + 1) * words_per_rank])
+                before = self.bytes_gathered
+                self.all_gather_device(buf, world * words_per_rank, words_per_rank)
+                self.bytes_gathered = before
+                good = bool((self.ctx.buffer_read(buf, world * words_per_rank) == want).all())
+                # every rank must take the same decision: the collectives of the two forms differ
+                agreed = int(self.sum_host(np.array([0 if good else 1], dtype=np.uint64))[0]) == 0
+                if agreed:
+                    return "staged" if self.staged else "in-place"
+                if self.staged:
+                    break
+                self.staged = True
+        finally:
+            self.ctx.buffer_free(buf)
+        raise RuntimeError("all-gather self-check failed in both the in-place and the staged form")
