@@ -18,10 +18,14 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass(NttPassParams p) {
     // the same coefficient slab, so the j-th block of XCD label x takes coset j % nz of slab (j / nz) * 8 + x: the slab is
     // fetched from HBM once and the other cosets hit L2, instead of nz HBM reads spread over the launch.
     const u32 lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), x = lin & 7, j = lin >> 3, nz = gridDim.z;
-    const u32 sc = (j / nz) * 8 + x;
-    z = j % nz + p.z_base;
-    wg = sc % gridDim.x;
-    col = sc / gridDim.x;
+    if (p.xcd_group == 2) {  // column before slab (see k_ntt_pass_pf)
+      z = j % nz + p.z_base; col = (j / nz) % gridDim.y; wg = (j / (nz * gridDim.y)) * 8 + x;
+    } else {
+      const u32 sc = (j / nz) * 8 + x;
+      z = j % nz + p.z_base;
+      wg = sc % gridDim.x;
+      col = sc / gridDim.x;
+    }
   }
   pass.template load<INV>(lds, tid, NTT_THREADS, wg, col, z);
   __syncthreads();
@@ -52,7 +56,14 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p,
   const u32 tid = threadIdx.x;
   auto coords = [&](u32 it, u32 &wg, u32 &col, u32 &z) {  // the slab of iteration `it`: the block mapping of k_ntt_pass
     const u32 lin = blockIdx.x + it * gridDim.x;
-    if (p.xcd_group) {
+    if (p.xcd_group == 2) {
+      // per XCD (label x = lin & 7) the slabs run coset-fastest, then column, then slab index: the 64 workgroups resident on an
+      // XCD at a time are 8 cosets x 8 columns of ONE slab index, so the coefficient slab of a column is fetched once for its
+      // 8 cosets, and the coset-scale rows and the inter-group twiddle row of that slab index - which depend on (z, wg) and on wg
+      // only, not on the column - are fetched once for all the columns of the launch instead of once per column
+      const u32 x = lin & 7, j = lin >> 3;
+      z = j % gz + p.z_base; col = (j / gz) % gy; wg = (j / (gz * gy)) * 8 + x;
+    } else if (p.xcd_group) {
       const u32 x = lin & 7, j = lin >> 3, sc = (j / gz) * 8 + x;
       z = j % gz + p.z_base; wg = sc % gx; col = sc / gx;
     } else {

@@ -7,6 +7,7 @@
 //   void Backend::launch_bitrev(const BitrevTile&, u32 wgs, u32 cols)      (lg >= 12)
 //   void Backend::launch_bitrev_small(in, out, strides, lg, cols)          (lg < 12)
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -182,6 +183,7 @@ struct NttHost {
       }
       // first pass of a full LDE: group the cosets of a slab on one XCD when the block count allows the bijection
       p.xcd_group = first && nz > 1 && ((u64)wgs * ncols) % 8 == 0 ? 1 : 0;
+      if (p.xcd_group && wgs % 8 == 0 && !getenv("LCP2_NTT_ORDER1")) p.xcd_group = 2;  // TEMP toggle for the A/B measurement
       be.launch_pass(false, p, wgs, ncols, nz);
     }
   }

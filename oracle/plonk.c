@@ -105,7 +105,8 @@ struct orc_circuit {
   uint64_t *imm; size_t num_imm;
   uint64_t *k_is;
   uint64_t *cs_values;       /* [NC + NR][n] */
-  orc_batch *cs;             /* constants_sigmas commitment */
+  orc_batch *cs;             /* constants_sigmas commitment (NULL in a verifier-only circuit) */
+  uint64_t *cs_cap;          /* its Merkle cap: all the verifier needs of the preprocessed polynomials */
   uint64_t digest[4];
   uint32_t max_gate_constraints;
   orc_challenges last;
@@ -134,7 +135,9 @@ static orc_circuit *circuit_new(const orc_params *p, const uint64_t *constants_s
    * [1, 0, 0, 0, 0, 0, 0, 1] */
   size_t capw = (size_t)4 << p->cap_height;
   uint64_t *buf = (uint64_t *)xmalloc((capw + 5) * 8);
-  memcpy(buf, c->cs->tree->cap, capw * 8);
+  c->cs_cap = (uint64_t *)xmalloc(capw * 8);
+  memcpy(c->cs_cap, c->cs->tree->cap, capw * 8);
+  memcpy(buf, c->cs_cap, capw * 8);
   const uint64_t empty_padded[8] = {1, 0, 0, 0, 0, 0, 0, 1};
   orc_hash_no_pad(empty_padded, 8, buf + capw);
   buf[capw + 4] = p->degree_bits;
@@ -153,13 +156,34 @@ orc_circuit *orc_circuit_new_unbuilt(const orc_params *p, const uint64_t *consta
                                      const uint64_t *imm, size_t num_imm, uint32_t npi) {
   return circuit_new(p, constants_sigmas, k_is, num_selectors, gates, num_gates, code, code_words, imm, num_imm, npi, 0);
 }
+/* Verifier-only circuit (= plonky2's VerifierCircuitData: VerifierOnlyCircuitData {constants_sigmas_cap, circuit_digest} +
+ * CommonCircuitData {config, gates, selectors, k_is, num_public_inputs}): no preprocessed values, no build().  orc_verify works
+ * on it at any size; orc_prove / orc_check_witness refuse it. */
+orc_circuit *orc_verifier_new(const orc_params *p, const uint64_t *k_is, uint32_t num_selectors, const orc_gate *gates,
+                              uint32_t num_gates, const uint32_t *code, size_t code_words, const uint64_t *imm, size_t num_imm,
+                              uint32_t npi, const uint64_t digest[4], const uint64_t *cap) {
+  if (p->num_challenges > 4 || p->num_query_rounds > 64 || p->num_fri_layers > ORC_MAX_FRI_LAYERS) return NULL;
+  if (p->quotient_degree_factor != (1u << p->rate_bits)) return NULL;
+  orc_circuit *c = (orc_circuit *)xcalloc(1, sizeof *c);
+  c->p = *p; c->n = (size_t)1 << p->degree_bits; c->num_selectors = num_selectors; c->num_gates = num_gates; c->npi = npi;
+  c->gates = (orc_gate *)xmalloc(num_gates * sizeof(orc_gate)); memcpy(c->gates, gates, num_gates * sizeof(orc_gate));
+  c->code = (uint32_t *)xmalloc(code_words * 4); memcpy(c->code, code, code_words * 4); c->code_words = code_words;
+  c->imm = (uint64_t *)xmalloc(num_imm * 8); for (size_t i = 0; i < num_imm; i++) c->imm[i] = gl_canon(imm[i]); c->num_imm = num_imm;
+  c->k_is = (uint64_t *)xmalloc(p->num_routed_wires * 8); for (uint32_t i = 0; i < p->num_routed_wires; i++) c->k_is[i] = gl_canon(k_is[i]);
+  for (uint32_t g = 0; g < num_gates; g++) if (gates[g].num_constraints > c->max_gate_constraints) c->max_gate_constraints = gates[g].num_constraints;
+  size_t capw = (size_t)4 << p->cap_height;
+  c->cs_cap = (uint64_t *)xmalloc(capw * 8);
+  memcpy(c->cs_cap, cap, capw * 8);
+  memcpy(c->digest, digest, 32);
+  return c;
+}
 void orc_circuit_free(orc_circuit *c) {
   if (!c) return;
-  free(c->gates); free(c->code); free(c->imm); free(c->k_is); free(c->cs_values); batch_free(c->cs); free(c);
+  free(c->gates); free(c->code); free(c->imm); free(c->k_is); free(c->cs_values); free(c->cs_cap); batch_free(c->cs); free(c);
 }
 void orc_circuit_digest(const orc_circuit *c, uint64_t digest[4], uint64_t *cap) {
   memcpy(digest, c->digest, 32);
-  if (cap) memcpy(cap, c->cs->tree->cap, ((size_t)4 << c->p.cap_height) * 8);
+  if (cap) memcpy(cap, c->cs_cap, ((size_t)4 << c->p.cap_height) * 8);
 }
 void orc_last_challenges(const orc_circuit *c, orc_challenges *out) { *out = c->last; }
 
@@ -354,6 +378,7 @@ static void eval_gates_ext(const orc_circuit *c, const gl2_t *wires, const gl2_t
 }
 
 size_t orc_check_witness(const orc_circuit *c, const uint64_t *wires, const uint64_t *pis_in, uint64_t first_bad[2]) {
+  if (!c->cs_values) return (size_t)-1; /* verifier-only circuit: no preprocessed values */
   size_t n = c->n, bad = 0;
   uint32_t W = c->p.num_wires, NC = c->p.num_constants;
   uint64_t *pis = (uint64_t *)xmalloc((c->npi + 1) * 8);
@@ -524,6 +549,7 @@ static uint64_t fri_proof_of_work(challenger *ch, unsigned pow_bits) {
 /* ------------------------------------------------------------------ prove */
 int orc_prove(const orc_circuit *cc, const uint64_t *wires_in, const uint64_t *pis_in, uint64_t *proof) {
   orc_circuit *c = (orc_circuit *)cc; /* only `last` is written */
+  if (!c->cs) return -1; /* verifier-only or unbuilt circuit */
   const orc_params *p = &c->p;
   size_t n = c->n, N = n << p->rate_bits, W = p->num_wires, NR = p->num_routed_wires, NC = p->num_constants, CH = p->num_challenges,
          Q = p->quotient_degree_factor;
@@ -827,7 +853,7 @@ int orc_verify(const orc_circuit *c, const uint64_t *proof, const uint64_t *pis_
       free(v);
     }
     gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(p->degree_bits));
-    const uint64_t *caps[4] = {c->cs->tree->cap, proof + L.wires_cap, proof + L.zs_cap, proof + L.quot_cap};
+    const uint64_t *caps[4] = {c->cs_cap, proof + L.wires_cap, proof + L.zs_cap, proof + L.quot_cap};
     gl2_t alpha_ch = gl2_pow(fri_alpha, CH);
     for (uint32_t q = 0; q < p->num_query_rounds && !rc; q++) {
       size_t x_index = (size_t)(ch_get(&ch) % N);

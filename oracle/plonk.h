@@ -51,6 +51,10 @@ orc_circuit *orc_circuit_new(const orc_params *p, const uint64_t *constants_sigm
 orc_circuit *orc_circuit_new_unbuilt(const orc_params *p, const uint64_t *constants_sigmas, const uint64_t *k_is,
                                      uint32_t num_selectors, const orc_gate *gates, uint32_t num_gates, const uint32_t *code,
                                      size_t code_words, const uint64_t *imm, size_t num_imm, uint32_t num_public_inputs);
+/* verifier-only circuit from the digest and the constants/sigmas cap (no preprocessed values, no build()): orc_verify only */
+orc_circuit *orc_verifier_new(const orc_params *p, const uint64_t *k_is, uint32_t num_selectors, const orc_gate *gates,
+                              uint32_t num_gates, const uint32_t *code, size_t code_words, const uint64_t *imm, size_t num_imm,
+                              uint32_t num_public_inputs, const uint64_t digest[4], const uint64_t *cap);
 void orc_circuit_free(orc_circuit *c);
 void orc_circuit_digest(const orc_circuit *c, uint64_t digest[4], uint64_t *cap /* 2^cap_height*4, nullable */);
 size_t orc_proof_words(const orc_params *p);

@@ -99,6 +99,34 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     data.verify(proof);  // assert!(data.verify(proof).is_ok())
     if (!oproof.empty() && proof.proof != oproof) throw std::runtime_error("GPU proof differs from the oracle proof");
     if (need_built && orc_verify(oc, proof.proof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the GPU proof");
+    {
+      // the independent verifier at ANY size: the oracle's verifier from digest + constants/sigmas cap alone (no oracle build()),
+      // as stock plonky2's VerifierCircuitData would check the proof (src/main.rs:233).  Accepts the GPU proof, rejects it after a
+      // one-word flip (an opening: the vanishing identity; a Merkle leaf word of the first query: the path check)
+      uint64_t digest[4];
+      std::vector<uint64_t> cap;
+      data.verifier_only_data(digest, cap);
+      orc_circuit *ov = orc_verifier_new(&op, D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(), D.imm.data(),
+                                         D.imm.size(), D.num_public_inputs, digest, cap.data());
+      if (!ov) throw std::runtime_error("orc_verifier_new rejected the description");
+      if (need_built) {  // where the oracle has built the circuit itself, the product's digest and cap must be the oracle's
+        uint64_t od[4];
+        std::vector<uint64_t> ocap(cap.size());
+        orc_circuit_digest(oc, od, ocap.data());
+        if (memcmp(od, digest, 32) != 0 || ocap != cap) throw std::runtime_error("product digest / constants cap differ from the oracle's build()");
+      }
+      int rc = orc_verify(ov, proof.proof.data(), pis.data());
+      if (rc != 0) throw std::runtime_error("oracle verifier (verifier-only) rejected the GPU proof, check " + std::to_string(rc));
+      lcp2_proof_layout L;
+      lcp2_proof_layout_of(&D.params, &L);
+      for (size_t w : {(size_t)L.op_wires + 3, (size_t)(L.queries + L.q_init_off[1] + 2)}) {
+        std::vector<uint64_t> bad_proof = proof.proof;
+        bad_proof[w] = bad_proof[w] == 5 ? 6 : 5;
+        if (orc_verify(ov, bad_proof.data(), pis.data()) == 0) throw std::runtime_error("oracle verifier accepted a proof with word " + std::to_string(w) + " changed");
+      }
+      orc_circuit_free(ov);
+      printf("oracle verifier (digest + cap only) accepted the GPU proof and rejected two one-word changes (degree_bits %u)\n", data.degree_bits());
+    }
   } else if (oproof.empty()) {
     printf("witness generated (host, %lld ms) and every gate constraint checked (oracle), degree_bits %u\n", witness_ms, data.degree_bits());
   } else {
@@ -294,7 +322,7 @@ static void test_read_u32_be_public_input() {
 // version, mainnet genesis_validators_root) -- with the BLS verifier stubbed any 32 bytes keep the circuit consistent.
 static void sha2(const uint8_t *l, const uint8_t *r, uint8_t *out) { orc_sha256_two_to_one(l, r, out); }
 enum LcVariant { LC_OK, LC_BAD_STATE_ROOT, LC_LOW_PARTICIPATION, LC_WITH_BLS_PROOF, LC_BLS_PROOF_OF_OTHER_BITS };
-static void light_client_update(LcVariant variant) {
+static void light_client_update(LcVariant variant, int extra_committees = 0) {
   // src/main.rs:170-176: the BLS-signature proof comes first (here: of the stand-in statement circuit), its common data shapes
   // the recursive verifier inside the light-client circuit
   const bool with_bls = variant == LC_WITH_BLS_PROOF || variant == LC_BLS_PROOF_OF_OTHER_BITS;
@@ -309,6 +337,13 @@ static void light_client_update(LcVariant variant) {
   ProofTarget target = add_virtual_proof_target(builder, with_bls ? &bls_cd : nullptr);
   for (auto &limb : target.cur_state) builder.register_public_input(limb.t);  // src/main.rs:180-187
   for (auto &limb : target.new_state) builder.register_public_input(limb.t);
+  // the reference's scale made of real gadgets (README.md:71, ~2.98 M gates): the step plus `extra_committees` more
+  // SyncCommitteeSSZ gadgets over the signing committee (as examples/lc_prover --extra-committees)
+  std::vector<SyncCommitteeTarget> more;
+  for (int k = 0; k < extra_committees; k++) {
+    more.push_back(add_virtual_sync_committee_target(builder));
+    ssz_sync_committee(builder, more.back());
+  }
   builder.print_gate_counts(0);
   auto data = builder.build();
 
@@ -350,6 +385,11 @@ static void light_client_update(LcVariant variant) {
                    LC634__FINALIZED_BODY_ROOT, LC634__FINALITY_BRANCH, cur_state, new_state, LC633__FINALIZED_SLOT, cur_header, cur_i, cur_ii,
                    new_i, new_ii, bits, LC634__NEXT_SYNC_COMMITTEE_BRANCH, LC633__NEXT_SYNC_COMMITTEE_PUBKEYS,
                    LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC634__SYNC_COMMITTEE_SIGNATURE, target);
+  for (const SyncCommitteeTarget &sc : more) {
+    for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++)
+      pw.set_target_arr(sc.pubkeys[i], std::vector<F>(LC633__NEXT_SYNC_COMMITTEE_PUBKEYS[i], LC633__NEXT_SYNC_COMMITTEE_PUBKEYS[i] + G1_PUBKEY_SIZE));
+    pw.set_target_arr(sc.aggregate_pubkey, std::vector<F>(LC633__NEXT_SYNC_COMMITTEE_AGGREGATE, LC633__NEXT_SYNC_COMMITTEE_AGGREGATE + G1_PUBKEY_SIZE));
+  }
   if (with_bls) {
     PartialWitness bpw;
     std::vector<bool> proved_bits = bits;
@@ -368,6 +408,16 @@ static void light_client_update(LcVariant variant) {
   g_skip_oracle_prove = false;
 }
 static void test_light_client_update() { light_client_update(LC_OK); }
+// GPU only: 7 207 two_to_one_sha256, 2.24 M gates, 2^22 rows.  The oracle checks every gate constraint of the witness row-wise,
+// the device witness equals the host generators' cell for cell, and the proof is accepted by the product's verifier and by the
+// oracle's verifier (from digest + cap alone: the oracle's own build() would take minutes at this size) and rejected by it after
+// a one-word change
+static void test_real_gadget_circuit_2p22() {
+  if (!g_gpu) { printf("(gpu only)\n"); return; }
+  setenv("LCP2_SKIP_ORACLE_BUILD", "1", 1);
+  try { light_client_update(LC_OK, 6); } catch (...) { unsetenv("LCP2_SKIP_ORACLE_BUILD"); throw; }
+  unsetenv("LCP2_SKIP_ORACLE_BUILD");
+}
 static void test_light_client_update_bad_state_root_panics() { light_client_update(LC_BAD_STATE_ROOT); }
 // src/targets.rs:304-332 update_validity and :184-235 find_sync_committee reject what they are there to reject
 static void test_light_client_update_low_participation_panics() { light_client_update(LC_LOW_PARTICIPATION); }
@@ -677,7 +727,7 @@ static void test_recursive_verifier_tampered_sibling_panics() { recursive_verifi
 static void test_recursive_verifier_wrong_public_input_panics() { recursive_verifier(false, false, -1, true); }
 static void test_recursive_verifier_wrong_digest_panics() { recursive_verifier(false, false, -1, false, true); }
 
-struct TestCase { const char *name; std::function<void()> fn; bool should_panic; };
+struct TestCase { const char *name; std::function<void()> fn; bool should_panic; bool gpu_only = false; };
 static const TestCase TESTS[] = {
     {"test_merkle_root_2_leaves", test_merkle_root_2_leaves, false},
     {"test_merkle_root_4_leaves", test_merkle_root_4_leaves, false},
@@ -729,13 +779,15 @@ static const TestCase TESTS[] = {
     {"test_recursive_verifier_tampered_sibling_panics", test_recursive_verifier_tampered_sibling_panics, true},
     {"test_recursive_verifier_wrong_public_input_panics", test_recursive_verifier_wrong_public_input_panics, true},
     {"test_recursive_verifier_wrong_digest_panics", test_recursive_verifier_wrong_digest_panics, true},
+    {"test_real_gadget_circuit_2p22", test_real_gadget_circuit_2p22, false, true},
 };
 
 int main(int argc, char **argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s <cpu|gpu> <test|all|list>\n", argv[0]); return 2; }
   g_gpu = std::string(argv[1]) == "gpu";
   std::string which = argv[2];
-  if (which == "list") { for (auto &t : TESTS) printf("%s\n", t.name); return 0; }
+  if (which == "list") { for (auto &t : TESTS) if (!t.gpu_only) printf("%s\n", t.name); return 0; }
+  if (which == "list-gpu-only") { for (auto &t : TESTS) if (t.gpu_only) printf("%s\n", t.name); return 0; }
   if (g_gpu) {
     int rc = lcp2_ctx_create(0, nullptr, &g_ctx);
     if (rc != LCP2_OK) { fprintf(stderr, "lcp2_ctx_create: %s\n", lcp2_status_str(rc)); return 3; }
@@ -743,6 +795,7 @@ int main(int argc, char **argv) {
   int failures = 0, ran = 0;
   for (auto &t : TESTS) {
     if (which != "all" && which != t.name) continue;
+    if (t.gpu_only && !g_gpu) continue;
     ran++;
     bool panicked = false;
     std::string msg;

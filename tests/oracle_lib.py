@@ -59,6 +59,7 @@ def load():
         "orc_fft_batch": (None, [V, c.c_size_t, c.c_size_t]),
         "orc_lde_batch": (None, [V, c.c_size_t, c.c_size_t, c.c_uint, c.c_uint64, V]),
         "orc_circuit_new": (V, [V, V, V, c.c_uint32, V, c.c_uint32, V, c.c_size_t, V, c.c_size_t, c.c_uint32]),
+        "orc_verifier_new": (V, [V, V, c.c_uint32, V, c.c_uint32, V, c.c_size_t, V, c.c_size_t, c.c_uint32, V, V]),
         "orc_circuit_free": (None, [V]),
         "orc_circuit_digest": (None, [V, V, V]),
         "orc_proof_words": (c.c_size_t, [V]),
@@ -160,6 +161,22 @@ class OracleCircuit:
                                    gs.imm.size, circ.num_public_inputs)
         assert self.h, "orc_circuit_new rejected the description"
         self.proof_words = L.orc_proof_words(c.byref(circ.params))
+
+    @classmethod
+    def verifier_only(cls, L, circ, digest, cap):
+        """the oracle's verifier from digest + constants/sigmas cap alone (plonky2's VerifierCircuitData): no preprocessed
+        values are read and nothing is committed, so it runs at any circuit size (oracle/plonk.c orc_verifier_new)"""
+        self = cls.__new__(cls)
+        self.L, self.params = L, circ.params
+        gs = circ.gateset
+        d = np.ascontiguousarray(digest, dtype=np.uint64)
+        cp = np.ascontiguousarray(cap, dtype=np.uint64)
+        assert d.size == 4 and cp.size == 4 << circ.params.cap_height
+        self.h = L.orc_verifier_new(c.byref(circ.params), vp(circ.k_is), gs.num_selectors, c.cast(circ.gates_array, c.c_void_p),
+                                    len(gs.gates), vp(gs.code), gs.code_len, vp(gs.imm), gs.imm.size, circ.num_public_inputs, vp(d), vp(cp))
+        assert self.h, "orc_verifier_new rejected the description"
+        self.proof_words = L.orc_proof_words(c.byref(circ.params))
+        return self
 
     def check_witness(self, wires, pis):
         bad = np.zeros(2, dtype=np.uint64)

@@ -206,6 +206,20 @@ def test_headline_size_proof_verifies(gpu_ctx):
     bad[3 * (4 << params.cap_height) + 7] ^= np.uint64(1)  # an opening
     with pytest.raises(m.ProofRejected):
         data.verify(bad, pis)
+    # the independent check at headline size (the reference ends with stock plonky2's data.verify, src/main.rs:233): the ORACLE's
+    # verifier, built from the digest and the constants/sigmas cap alone (no oracle build(), which would take minutes here),
+    # accepts the GPU proof and rejects it after a one-word change
+    import oracle_lib
+    digest, cap = data.digest()
+    ov = oracle_lib.OracleCircuit.verifier_only(oracle_lib.load(), circ, digest, cap)
+    assert ov.verify(proof, pis) == 0
+    assert ov.verify(bad, pis) != 0          # an opening: the vanishing identity
+    assert ov.verify(proof, wrong) != 0      # a public input: the transcript
+    lay = m.proof_layout(params)
+    bad2 = proof.copy()
+    bad2[lay.queries + lay.q_init_off[1] + 2] ^= np.uint64(1)  # a wires leaf word of the first query: the Merkle path
+    assert ov.verify(bad2, pis) != 0
+    ov.close()
     data.close()
     del w_dev
     torch.cuda.empty_cache()

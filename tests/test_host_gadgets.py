@@ -32,9 +32,14 @@ CPU_TESTS = [
 ]
 
 
+# the reference's scale made of real gadgets (2.24 M gates, 2^22 rows): GPU prove, device witness = host witness, oracle verifier
+GPU_ONLY_TESTS = ["test_real_gadget_circuit_2p22"]
+
+
 def test_test_list_is_complete():
     out = cpp_build.run("cpu", "list").stdout.split()
     assert out == CPU_TESTS
+    assert cpp_build.run("cpu", "list-gpu-only").stdout.split() == GPU_ONLY_TESTS
 
 
 @pytest.mark.parametrize("name", CPU_TESTS)
@@ -50,5 +55,10 @@ def test_gadgets_gpu_all():
     # 633 -> 634, BLS verifier stubbed) end to end on the GPU
     r = cpp_build.run("gpu", "all", timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    for name in CPU_TESTS:
+    for name in CPU_TESTS + GPU_ONLY_TESTS:
         assert f"test {name} ... ok" in r.stdout
+    # every proving test ends with the oracle's verifier (built from digest + cap alone) accepting the GPU proof and rejecting two
+    # one-word changes; the 2^19-row light-client proofs and the 2^22-row real-gadget proof are among them
+    assert r.stdout.count("oracle verifier (digest + cap only) accepted the GPU proof") >= 20
+    assert "rejected two one-word changes (degree_bits 22)" in r.stdout
+    assert "rejected two one-word changes (degree_bits 19)" in r.stdout

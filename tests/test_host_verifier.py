@@ -36,6 +36,40 @@ def test_product_verifier_accepts_oracle_proofs(oracle, degree_bits):
     vd.close()
 
 
+def test_oracle_verifier_only_circuit_agrees_with_the_built_one(oracle):
+    """orc_verifier_new: the oracle's verifier from digest + cap alone (what the GPU tests use at 2^19 / 2^22 rows, where the
+    oracle's build() would take minutes) gives the same verdict, check for check, as the oracle circuit that built the
+    commitment itself; it refuses to prove."""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(7, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=77)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    proof = oc.prove(wires, pis)
+    digest, cap = oc.digest()
+    ov = oracle_lib.OracleCircuit.verifier_only(oracle, circ, digest, cap)
+    assert ov.verify(proof, pis) == 0
+    lay = m.proof_layout(params)
+    spots = [0, lay.zs_cap + 1, lay.quot_cap + 2, lay.op_wires + 3, lay.op_quotient + 1, lay.fri_caps + 5, lay.final_poly, lay.pow_witness,
+             lay.queries + lay.q_init_off[0] + 1, lay.queries + lay.q_init_off[1] + lay.q_init_cols[1] + 2, lay.queries + lay.q_step_off[0] + 3,
+             lay.queries + 5 * lay.query_words + lay.q_init_off[3]]
+    for pos in spots:
+        bad = proof.copy()
+        bad[pos] ^= np.uint64(1)
+        assert ov.verify(bad, pis) == oc.verify(bad, pis) != 0, pos
+    wrong_digest = digest.copy()
+    wrong_digest[2] ^= np.uint64(1)
+    ov2 = oracle_lib.OracleCircuit.verifier_only(oracle, circ, wrong_digest, cap)
+    assert ov2.verify(proof, pis) != 0
+    wrong_cap = cap.copy()
+    wrong_cap[3, 1] ^= np.uint64(1)
+    ov3 = oracle_lib.OracleCircuit.verifier_only(oracle, circ, digest, wrong_cap)
+    assert ov3.verify(proof, pis) != 0  # the constants/sigmas Merkle paths no longer end in the cap (unless no query lands under entry 3)
+    out = np.zeros(ov.proof_words, dtype=np.uint64)
+    assert oracle.orc_prove(ov.h, oracle_lib.vp(wires), oracle_lib.vp(pis), oracle_lib.vp(out)) != 0
+    for x in (oc, ov, ov2, ov3):
+        x.close()
+
+
 def test_unsatisfied_witness_is_rejected(oracle):
     import eth_lc_plonky2_amd as m
     params = m.standard_params(6, 4)
