@@ -2,7 +2,6 @@
 // decomposition.  One workgroup = one 2^L-element slab in LDS (up to 68 KiB with padding, so two
 // workgroups share a CU's 160 KiB), NTT_THREADS threads, one barrier per register step (3-4 stages).
 // Global traffic is one read and one write of the slab per pass, in runs of >= 128 bytes.
-#include <cstdlib>
 #include "internal.hpp"
 
 namespace lcp2 {
@@ -44,12 +43,13 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// The passes of a large transform (2^13-element slabs: 3 + 3 + 3 strided bits over 16-element runs, or 3 + 3 + 3 + 4 contiguous
-// bits) with SEVERAL slabs per workgroup and the next slab's elements prefetched into registers while the current one is in its
-// register steps: with two workgroups per CU (the slab fills the LDS) nothing else hides the HBM latency of the load phase,
-// which costs 18 % of the LDE when exposed.  FACTORS: the load multiplies by a one-level factor table (the coset scale of an
-// LDE's first pass, the inter-group twiddle of an inverse strided pass).
-template <bool INV, bool STRIDED, bool FACTORS>
+// The forward passes of a large transform (2^13-element slabs: 3 + 3 + 3 strided bits over 16-element runs, or 3 + 3 + 3 + 4
+// contiguous bits) with SEVERAL slabs per workgroup and the next slab's elements prefetched into registers while the current one
+// is in its register steps: with two workgroups per CU (the slab fills the LDS) nothing else hides the HBM latency of the load
+// phase.  The first step runs on the prefetched registers and the last one stores from registers (strided) or through the wave's
+// own LDS region (contiguous): see ntt.hpp.  Barriers per slab: 3 (strided) / 4 (contiguous), LDS round trips 2 / 4.
+// FMODE: coset scale of an LDE's first pass (0 none, 1 one-level table, 2 computed from one table value per thread).
+template <bool STRIDED, int FMODE>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p, u32 gx, u32 gy, u32 gz, u32 slabs_per_wg) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   NttPass pass{p};
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p,
       // per XCD (label x = lin & 7) the slabs run coset-fastest, then column, then slab index: the 64 workgroups resident on an
       // XCD at a time are 8 cosets x 8 columns of ONE slab index, so the coefficient slab of a column is fetched once for its
       // 8 cosets, and the coset-scale rows and the inter-group twiddle row of that slab index - which depend on (z, wg) and on wg
-      // only, not on the column - are fetched once for all the columns of the launch instead of once per column
+      // only, not on the column - are shared by the columns in flight instead of fetched once per column
       const u32 x = lin & 7, j = lin >> 3;
       z = j % gz + p.z_base; col = (j / gz) % gy; wg = (j / (gz * gy)) * 8 + x;
     } else if (p.xcd_group) {
@@ -74,39 +74,40 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p,
   u32 wg, col, z;
   coords(0, wg, col, z);
   pass.prefetch(tid, NTT_THREADS, wg, col, z, v);
+  u64 *twl = lds + ntt_lds_words(13);  // compact step twiddles behind the slab (ntt.hpp pf_stage_twiddles); the first barrier publishes them
+  pass.template pf_stage_twiddles<STRIDED>(twl, tid);
+  if (STRIDED) lds_barrier();  // the first step of a strided pass reads them already
+  // Everything a phase derives from the thread id alone - 64-bit twiddle addresses above all, two dozen per step - is loop invariant,
+  // and hipcc hoists all of it out of the slab loop and then spills it (100 VGPRs of scratch, reloaded for every slab).  The thread
+  // id is therefore made opaque once per phase: the addresses are recomputed (one or two instructions each) where they are used.
+  auto fresh_tid = [&]() { u32 t = tid; asm volatile("" : "+v"(t)); return t; };
   for (u32 it = 0; it < slabs_per_wg; it++) {
-    pass.template commit<INV, FACTORS>(lds, tid, NTT_THREADS, wg, z, v);
+    pass.template pf_first_step<STRIDED, FMODE>(lds, fresh_tid(), wg, z, v, STRIDED ? twl : p.group_tw);
     lds_barrier();
     u32 nwg = wg, ncol = col, nz = z;
     if (it + 1 < slabs_per_wg) {
       coords(it + 1, nwg, ncol, nz);
-      pass.prefetch(tid, NTT_THREADS, nwg, ncol, nz, v);
+      pass.prefetch(fresh_tid(), NTT_THREADS, nwg, ncol, nz, v);
     }
-    if (STRIDED) {  // S = 4, B = 9: steps of 3 bits at local bits 10, 7, 4
-      if (!INV) {
-        pass.template step_r<false, 3, 10>(lds, tid, NTT_THREADS, 8); lds_barrier();
-        pass.template step_r<false, 3, 7>(lds, tid, NTT_THREADS, 5); lds_barrier();
-        pass.template step_r<false, 3, 4>(lds, tid, NTT_THREADS, 2); lds_barrier();
-      } else {
-        pass.template step_r<true, 3, 4>(lds, tid, NTT_THREADS, 2); lds_barrier();
-        pass.template step_r<true, 3, 7>(lds, tid, NTT_THREADS, 5); lds_barrier();
-        pass.template step_r<true, 3, 10>(lds, tid, NTT_THREADS, 8); lds_barrier();
-      }
-    } else {        // S = 0, B = 13: 3 + 3 + 3 bits at 10, 7, 4 and the 4 bottom bits
-      if (!INV) {
-        pass.template step_r<false, 3, 10>(lds, tid, NTT_THREADS, 12); lds_barrier();
-        pass.template step_r<false, 3, 7>(lds, tid, NTT_THREADS, 9); lds_barrier();
-        pass.template step_r<false, 3, 4>(lds, tid, NTT_THREADS, 6); lds_barrier();
-        pass.template step_r<false, 4, 0>(lds, tid, NTT_THREADS, 3); lds_barrier();
-      } else {
-        pass.template step_r<true, 4, 0>(lds, tid, NTT_THREADS, 3); lds_barrier();
-        pass.template step_r<true, 3, 4>(lds, tid, NTT_THREADS, 6); lds_barrier();
-        pass.template step_r<true, 3, 7>(lds, tid, NTT_THREADS, 9); lds_barrier();
-        pass.template step_r<true, 3, 10>(lds, tid, NTT_THREADS, 12); lds_barrier();
-      }
+    if (STRIDED) {  // S = 4, B = 9: the remaining steps at local bits 7 and 4
+      pass.template pf_mid_step<7>(lds, fresh_tid(), 5, twl + 512);
+      lds_barrier();
+      u64 x[16];
+      const u32 t = fresh_tid();
+      pass.pf_last_strided_read(lds, t, x);
+      lds_barrier();  // the slab has been read out: the next first step may overwrite it
+      pass.pf_last_strided_store(t, wg, col, z, x);
+    } else {        // S = 0, B = 13: 3 + 3 bits at 7 and 4, then the 4 bottom bits
+      pass.template pf_mid_step<7>(lds, fresh_tid(), 9, twl);
+      lds_barrier();
+      pass.template pf_mid_step<4>(lds, fresh_tid(), 6, twl + 1024);
+      lds_barrier();
+      const u32 t = fresh_tid();
+      pass.pf_last_contiguous(lds, t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local: the rows below were written by this wave (LDS is in order per wave)
+      pass.pf_store_wave_rows(lds, t, wg, col, z);
+      lds_barrier();  // the slab has been read out: the next first step may overwrite it
     }
-    pass.template store<INV>(lds, tid, NTT_THREADS, wg, col, z);
-    lds_barrier();  // the slab has been read out: the next commit may overwrite it
     wg = nwg; col = ncol; z = nz;
   }
 }
@@ -128,30 +129,21 @@ __global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restri
 
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
   size_t lds_bytes = (size_t)8 * ntt_lds_words(p.L);
-  // the prefetching form: the slab shapes of a large transform, factors (if any) from one-level tables, and enough slabs that
-  // the shorter grid still fills the chip
   const u64 total = (u64)wgs * cols * nz;
-  const bool strided = p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333;
-  const bool contiguous = p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0;
-  const bool factor = inverse ? p.g_lo != 0 : p.scale_mode != 0;
-  const bool direct = inverse ? p.tw.h == NTT_DIRECT : (p.scale_mode == 2 && p.sc.h == NTT_DIRECT);
-  // (forward passes only: the inverse instantiations need 30-odd more VGPRs than the 128 of four waves per SIMD and lose to the
-  // plain kernel once they spill)
-  static const int pf_mask = getenv("LCP2_NTT_PF") ? atoi(getenv("LCP2_NTT_PF")) : 3;  // debugging aid: bit 0 strided, bit 1 contiguous form
-  if (!inverse && ((strided && (pf_mask & 1)) || (contiguous && (pf_mask & 2))) && (!factor || (direct && strided)) && total < (1ull << 31)) {
-    // slabs per workgroup: only the first load of a workgroup is exposed, so as many as still leave 2048 workgroups (4 rounds
-    // of the 512 resident ones) and divide the slab count into a multiple of 8 workgroups (the XCD mapping)
-    u32 spw = 0;
-    for (u32 k = 16; k >= 2 && !spw; k >>= 1)
-      if (total % (k * 8) == 0 && total / k >= 2048) spw = k;
-    if (spw) {
-      const dim3 grid((u32)(total / spw));
-#define LCP2_PF(INV, STR, FAC) hipLaunchKernelGGL((k_ntt_pass_pf<INV, STR, FAC>), grid, dim3(NTT_THREADS), lds_bytes, s, p, wgs, cols, nz, spw)
-      if (strided) { if (factor) LCP2_PF(false, true, true); else LCP2_PF(false, true, false); }
-      else LCP2_PF(false, false, false);
-#undef LCP2_PF
-      return;
+  const u32 spw = ntt_pf_slabs_per_wg(p, inverse, total);
+  if (spw) {
+    const dim3 grid((u32)(total / spw));
+    lds_bytes += 8 * (ntt_pf_strided(p) ? NttPass::PF_TW_WORDS_STRIDED : NttPass::PF_TW_WORDS_CONTIGUOUS);  // 2 x 77 KiB still share a CU
+#define LCP2_PF(STR, FM) hipLaunchKernelGGL((k_ntt_pass_pf<STR, FM>), grid, dim3(NTT_THREADS), lds_bytes, s, p, wgs, cols, nz, spw)
+    if (ntt_pf_strided(p)) {
+      if (!p.scale_mode) LCP2_PF(true, 0);
+      else if (p.sc_step) LCP2_PF(true, 2);
+      else LCP2_PF(true, 1);
+    } else {
+      LCP2_PF(false, 0);
     }
+#undef LCP2_PF
+    return;
   }
   dim3 grid(wgs, cols, nz);
   if (inverse) hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), lds_bytes, s, p);

@@ -53,7 +53,11 @@ struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h];  h = NTT_D
   u32 h;
 };
 constexpr u32 NTT_DIRECT = 63;
-constexpr u32 NTT_DIRECT_MAX_LG = 22;  // one-level tables up to 2^22 entries (32 MiB) per table row
+constexpr u32 NTT_DIRECT_MAX_LG = 22;
+#ifndef LCP2_NTT_PF_COMPUTED_SCALE
+#define LCP2_NTT_PF_COMPUTED_SCALE 0
+#endif
+constexpr bool NTT_PF_COMPUTED_SCALE = LCP2_NTT_PF_COMPUTED_SCALE;  // coset scale of the prefetching kernel: 0 one-level table, 1 computed (FMODE 2)  // one-level tables up to 2^22 entries (32 MiB) per table row
 
 struct NttPassParams {
   const u64 *in;
@@ -73,6 +77,8 @@ struct NttPassParams {
   u64 scale_scalar;
   TwoLevelTable sc;                   // forward: applied at load; inverse: at store
   u64 sc_lo_z_stride, sc_hi_z_stride;
+  const u64 *sc_step;                 // [z][16]: shift_z^(k * 2^(g_lo + 5)), the ratio between a thread's elements in the fused first step
+                                      // of k_ntt_pass_pf (nullptr: the factors come from the one-level table)
 };
 
 LCP2_HD u32 lds_phys(u32 i) { return i + (i >> 4); }
@@ -250,36 +256,171 @@ struct NttPass {
     }
   }
 
-  // The load phase in two halves for the prefetching kernel (kernels_ntt.hip k_ntt_pass_pf): `prefetch` issues the loads of a
-  // thread's 16 elements of a 2^13 slab into registers and returns, `commit` turns them into the canonical, pre-multiplied LDS
-  // image.  Same addressing as the constant-stride walk of load().  The one-level factors are fetched in commit, 8 at a time
-  // (the tables are shared by every column and mostly cache resident; holding them across the register steps as well would
-  // cost 32 more VGPRs than the kernel has).
+  // ---- The phases of the prefetching kernel (kernels_ntt.hip k_ntt_pass_pf): forward passes over 2^13-element slabs with 512
+  // threads, STRIDED = (S 4, B 9: steps of 3 bits at local bits 10, 7, 4) or contiguous (S 0, B 13: 3 + 3 + 3 + 4 bits).
+  // A thread's 16 prefetched elements (local indices tid + 512 k) are exactly two groups of the FIRST register step (k even /
+  // k odd: local bits 10..12 = k >> 1), so that step runs on the prefetched registers and the slab reaches LDS already
+  // transformed: one LDS round trip and one barrier less than load -> LDS -> step.  Likewise the LAST step of a strided pass
+  // (bits 4..6: the 8 elements of a group are 8 runs apart in memory, the 64 lanes of a wave cover four 128-byte runs of each)
+  // stores straight from registers, and the last step of a contiguous pass (16 consecutive elements per thread) is followed by
+  // a transposition through the wave's OWN 1024-element region of the slab, which needs no workgroup barrier.
   LCP2_HD void prefetch(u32 tid, u32 nthr, u32 wg, u32 col, u32 z, u64 *v) const {
     const u64 *src = p.in + (u64)col * p.in_col_stride + (u64)z * p.in_z_stride;
     const u64 g0 = global_index(wg, tid), gs = (u64)(nthr >> p.S) << p.g_lo;
 #pragma unroll
     for (u32 j = 0; j < 16; j++) v[j] = src[g0 + j * gs];
   }
-  template <bool INV, bool FACTORS>
-  LCP2_HD void commit(u64 *lds, u32 tid, u32 nthr, u32 wg, u32 z, const u64 *v) const {
-    const u32 ph0 = lds_phys(tid), ps = nthr + (nthr >> 4);
-    if (FACTORS) {
-      const u64 gs = (u64)(nthr >> p.S) << p.g_lo;
-      const u64 *fac = INV ? p.tw.lo + (((u64)((tid >> p.S) & ((1u << p.B) - 1)) << p.g_lo) | low_bits(wg, tid))
-                           : p.sc.lo + (u64)z * p.sc_lo_z_stride + global_index(wg, tid);
-#pragma unroll
-      for (u32 h = 0; h < 16; h += 8) {
-        u64 f[8];
-#pragma unroll
-        for (u32 j = 0; j < 8; j++) f[j] = fac[(h + j) * gs];
-#pragma unroll
-        for (u32 j = 0; j < 8; j++) lds[ph0 + (h + j) * ps] = gl_mul(v[h + j], f[j]);
-      }
+  // FMODE 0: no factor (elements made canonical); 1: coset scale from the one-level table (one load and one multiply per
+  // element); 2: coset scale computed: shift^(g0 + k gs) = shift^g0 (one table load per thread) x (shift^gs)^k (wave-uniform
+  // scalars), with the thread's common factor carried through the linear transform into the step twiddles
+  // The step twiddles of the lower steps are a strided subset of p.group_tw (w_{2^B}^(e << shift)): read from there they cost an
+  // L2 round trip per step (a 64 KiB table walked with a stride of 8 or 64 entries does not live in the 32 KiB vector cache).
+  // The workgroup keeps compact copies in the LDS left beside the slab (12 KiB per workgroup with two per CU):
+  //   strided    [0, 512)   first step  w_512^e          [512, 576)    step at bit 7  w_64^e
+  //   contiguous [0, 1024)  step at bit 7  w_1024^e      [1024, 1152)  step at bit 4  w_128^e   (the first step spans the whole table)
+  static constexpr u32 PF_TW_WORDS_STRIDED = 576, PF_TW_WORDS_CONTIGUOUS = 1152;
+  template <bool STRIDED>
+  LCP2_HD void pf_stage_twiddles(u64 *twl, u32 tid) const {
+    if (STRIDED) {
+      twl[tid] = p.group_tw[tid];
+      if (tid < 64) twl[512 + tid] = p.group_tw[tid << 3];
     } else {
-#pragma unroll
-      for (u32 j = 0; j < 16; j++) lds[ph0 + j * ps] = gl_canon(v[j]);
+      twl[tid] = p.group_tw[tid << 3];
+      twl[512 + tid] = p.group_tw[(512 + tid) << 3];
+      if (tid < 128) twl[1024 + tid] = p.group_tw[tid << 6];
     }
+  }
+  // twt: the step twiddles w^(m * bitrev(j)) of the step, indexed by the exponent (p.group_tw itself for the top step, or the
+  // workgroup's compact copy in LDS, pf_stage_twiddles)
+  template <bool STRIDED, int FMODE>
+  LCP2_HD void pf_first_step(u64 *lds, u32 tid, u32 wg, u32 z, const u64 *v, const u64 *twt) const {
+    constexpr u32 PS = 512 + 32;  // lds_phys(tid + 512 k) = lds_phys(tid) + k * PS
+    const u32 ph0 = lds_phys(tid);
+    const u64 gs = (u64)(512u >> p.S) << p.g_lo;
+    const u64 *fac = FMODE ? p.sc.lo + (u64)z * p.sc_lo_z_stride + global_index(wg, tid) : nullptr;
+    const u64 *stp = FMODE == 2 ? p.sc_step + 16 * (u64)z : nullptr;
+    u64 f0 = 1;
+    if (FMODE == 2) f0 = fac[0];
+#pragma unroll
+    for (u32 b = 0; b < 2; b++) {
+      const u32 m = STRIDED ? ((tid >> 4) | (b << 5)) : (tid | (b << 9));  // group bits below the step
+      u64 x[8], tw[8], f[8];
+#pragma unroll
+      for (u32 j = 1; j < 8; j++) tw[j] = twt[m * bitrev32(j, 3)];
+      if (FMODE == 1) {
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) f[j] = fac[(2 * j + b) * gs];
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) x[j] = gl_mul(v[2 * j + b], f[j]);
+      } else if (FMODE == 2) {
+        x[0] = gl_canon(v[b]);
+#pragma unroll
+        for (u32 j = 1; j < 8; j++) x[j] = gl_mul(v[2 * j + b], stp[2 * j]);
+      } else {
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) x[j] = gl_canon(v[2 * j + b]);
+      }
+      ntt_reg_dif<3>(x);
+      if (FMODE == 2) {
+        const u64 fb = b ? gl_mul(f0, stp[1]) : gl_canon(f0);
+        x[0] = gl_mul(x[0], fb);
+#pragma unroll
+        for (u32 j = 1; j < 8; j++) x[j] = gl_mul(x[j], gl_mul_nc(tw[j], fb));
+      } else {
+#pragma unroll
+        for (u32 j = 1; j < 8; j++) x[j] = gl_mul(x[j], tw[j]);
+      }
+#pragma unroll
+      for (u32 j = 0; j < 8; j++) lds[ph0 + (2 * j + b) * PS] = x[j];
+    }
+  }
+  // a middle step: 3 bits at local bit P (7 or 4): the two groups of a thread, the LDS reads and twiddle loads of the second one
+  // issued before the transform of the first
+  template <u32 P>
+  LCP2_HD void pf_mid_step(u64 *lds, u32 tid, u32 kb_top, const u64 *twt) const {
+    constexpr u32 PSTRIDE = (1u << P) + (1u << (P - 4));
+    const u32 mbits = kb_top - 2;
+    u64 x0[8], x1[8], tw0[8], tw1[8];
+    const u32 b0 = ((tid >> P) << (P + 3)) | (tid & ((1u << P) - 1)), g1 = tid + 512, b1 = ((g1 >> P) << (P + 3)) | (g1 & ((1u << P) - 1));
+    const u32 p0 = lds_phys(b0), p1 = lds_phys(b1);
+    const u32 m0 = (b0 >> p.S) & ((1u << mbits) - 1), m1 = (b1 >> p.S) & ((1u << mbits) - 1);
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) x0[j] = lds[p0 + j * PSTRIDE];
+    if (mbits) {
+#pragma unroll
+      for (u32 j = 1; j < 8; j++) tw0[j] = twt[m0 * bitrev32(j, 3)];
+    }
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) x1[j] = lds[p1 + j * PSTRIDE];
+    if (mbits) {
+#pragma unroll
+      for (u32 j = 1; j < 8; j++) tw1[j] = twt[m1 * bitrev32(j, 3)];
+    }
+    ntt_reg_dif<3>(x0);
+    if (mbits) {
+#pragma unroll
+      for (u32 j = 1; j < 8; j++) x0[j] = gl_mul(x0[j], tw0[j]);
+    }
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) lds[p0 + j * PSTRIDE] = x0[j];
+    ntt_reg_dif<3>(x1);
+    if (mbits) {
+#pragma unroll
+      for (u32 j = 1; j < 8; j++) x1[j] = gl_mul(x1[j], tw1[j]);
+    }
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) lds[p1 + j * PSTRIDE] = x1[j];
+  }
+  // last step of a strided pass (bits 4..6, no step twiddle) in two halves: the LDS reads, then - after the barrier that lets
+  // the next slab in - transform, inter-group twiddle and the global stores from registers
+  LCP2_HD void pf_last_strided_read(const u64 *lds, u32 tid, u64 *x) const {
+#pragma unroll
+    for (u32 q = 0; q < 2; q++) {
+      const u32 g = tid + 512 * q, base = ((g >> 4) << 7) | (g & 15), pb = lds_phys(base);
+#pragma unroll
+      for (u32 j = 0; j < 8; j++) x[8 * q + j] = lds[pb + j * 17];
+    }
+  }
+  LCP2_HD void pf_last_strided_store(u32 tid, u32 wg, u32 col, u32 z, u64 *x) const {
+    u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)(bitrev32(z, p.zbits) - p.out_block_base) * p.out_z_stride;
+    const bool direct = p.tw.h == NTT_DIRECT;
+#pragma unroll
+    for (u32 q = 0; q < 2; q++) {
+      const u32 g = tid + 512 * q, base = ((g >> 4) << 7) | (g & 15);
+      const u64 g0 = global_index(wg, base), gs = (u64)1 << p.g_lo;  // element j of the group: local base | j << 4, one run further
+      u64 tw[8];
+      if (direct) {
+        const u64 *fac = p.tw.lo + (((u64)((base >> 4) & 511) << p.g_lo) | low_bits(wg, base));
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) tw[j] = fac[j * gs];
+      } else {
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) tw[j] = group_twiddle(wg, base | (j << 4));
+      }
+      ntt_reg_dif<3>(x + 8 * q);
+#pragma unroll
+      for (u32 j = 0; j < 8; j++) dst[g0 + j * gs] = gl_mul(x[8 * q + j], tw[j]);
+    }
+  }
+  // last step of a contiguous pass (bits 0..3: 16 consecutive elements per thread, no twiddle), written back into the wave's own
+  // region, and the store of that region in runs of 512 bytes per wave instruction (reads only what the same wave wrote)
+  LCP2_HD void pf_last_contiguous(u64 *lds, u32 tid) const {
+    const u32 pb = lds_phys(tid << 4);
+    u64 x[16];
+#pragma unroll
+    for (u32 j = 0; j < 16; j++) x[j] = lds[pb + j];
+    ntt_reg_dif<4>(x);
+#pragma unroll
+    for (u32 j = 0; j < 16; j++) lds[pb + j] = x[j];
+  }
+  LCP2_HD void pf_store_wave_rows(const u64 *lds, u32 tid, u32 wg, u32 col, u32 z) const {
+    u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)(bitrev32(z, p.zbits) - p.out_block_base) * p.out_z_stride + ((u64)wg << 13);
+    const u32 i0 = ((tid >> 6) << 10) | (tid & 63);  // element 64 k + lane of the wave's 1024
+    u64 v[16];
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) v[k] = lds[lds_phys(i0 + 64 * k)];
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) dst[i0 + 64 * k] = v[k];
   }
 
   // Register step over the RB group bits whose top one is kb_top (group-relative): see the header comment.
@@ -392,6 +533,25 @@ struct NttPass {
     }
   }
 };
+
+// ---- which launches take the prefetching kernel (shared by the library and the emulation harness) ----
+// The slab shapes of a large forward transform, factors (if any) from a one-level table, and enough slabs that the shorter
+// grid still fills the chip.  (Forward passes only: the inverse instantiations need more VGPRs than four waves per SIMD leave.)
+inline bool ntt_pf_strided(const NttPassParams &p) { return p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333; }
+inline bool ntt_pf_contiguous(const NttPassParams &p) {
+  return p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0 && p.scale_mode == 0;
+}
+// slabs per workgroup of the prefetching form, 0 = the launch takes the plain kernel.  Only the first load of a workgroup is
+// exposed, so as many as still leave 2048 workgroups (4 rounds of the 512 resident ones) and divide the slab count into a
+// multiple of 8 workgroups (the XCD mapping).
+inline u32 ntt_pf_slabs_per_wg(const NttPassParams &p, bool inverse, u64 total) {
+  if (inverse || total >= (1ull << 31)) return 0;
+  const bool strided = ntt_pf_strided(p) && p.g_lo != 0 && (p.scale_mode == 0 || (p.scale_mode == 2 && p.sc.h == NTT_DIRECT));
+  if (!strided && !ntt_pf_contiguous(p)) return 0;
+  for (u32 k = 16; k >= 2; k >>= 1)
+    if (total % (k * 8) == 0 && total / k >= 2048) return k;
+  return 0;
+}
 
 // ---- host-side pass planning (shared by the library and the emulation harness) ----
 struct NttGroup {

@@ -7,7 +7,6 @@
 //   void Backend::launch_bitrev(const BitrevTile&, u32 wgs, u32 cols)      (lg >= 12)
 //   void Backend::launch_bitrev_small(in, out, strides, lg, cols)          (lg < 12)
 #pragma once
-#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -26,6 +25,7 @@ inline std::vector<u64> make_pow_table(u64 base, u64 first, size_t count, u64 sc
 template <class Backend>
 struct NttHost {
   Backend &be;
+  bool computed_scale = NTT_PF_COMPUTED_SCALE;  // coset scale of the prefetching kernel computed instead of read (ntt.hpp pf_first_step)
   explicit NttHost(Backend &b) : be(b) {}
 
   static std::string key(const char *what, u64 a, u64 b, u64 c = 0) {
@@ -133,6 +133,20 @@ struct NttHost {
     return t;
   }
 
+  // [z][16]: shift_z^(k * 2^step_lg): the ratio between the 16 elements a thread of the prefetching kernel holds (ntt.hpp pf_first_step)
+  const u64 *shift_step_table(u64 base, u32 lg, u32 zbits, u32 step_lg) {
+    return be.table(key("shstep", base, lg * 64 + zbits, step_lg), [=] {
+      std::vector<u64> all;
+      for (u32 z = 0; z < (1u << zbits); z++) {
+        u64 sft = base;
+        if (zbits) sft = gl_mul(sft, gl_pow(gl_root_of_unity(lg + zbits), z));
+        auto v = make_pow_table(sft, 1ull << step_lg, 16);
+        all.insert(all.end(), v.begin(), v.end());
+      }
+      return all;
+    });
+  }
+
   // Forward coset NTT, natural in -> bit-reversed out.
   //   zbits = 0: one transform of size 2^lg per column, out[col] has 2^lg elements.
   //   zbits = r: low-degree extension: 2^r coset transforms of the same 2^lg coefficients,
@@ -163,6 +177,7 @@ struct NttHost {
         if (shift != 1 || zbits) {
           p.scale_mode = 2;
           p.sc = shift_table(shift, lg, zbits, false, 1, p.sc_lo_z_stride, p.sc_hi_z_stride, true);
+          if (computed_scale && p.sc.h == NTT_DIRECT && ntt_pf_strided(p)) p.sc_step = shift_step_table(shift, lg, zbits, g.g_lo + 5);
         }
         wgs = 1u << (lg - g.L);
         nz = 1u << zbits;
@@ -183,7 +198,7 @@ struct NttHost {
       }
       // first pass of a full LDE: group the cosets of a slab on one XCD when the block count allows the bijection
       p.xcd_group = first && nz > 1 && ((u64)wgs * ncols) % 8 == 0 ? 1 : 0;
-      if (p.xcd_group && wgs % 8 == 0 && !getenv("LCP2_NTT_ORDER1")) p.xcd_group = 2;  // TEMP toggle for the A/B measurement
+      if (p.xcd_group && wgs % 8 == 0) p.xcd_group = 2;  // column before slab index: the factor rows of a slab index are shared by the columns
       be.launch_pass(false, p, wgs, ncols, nz);
     }
   }

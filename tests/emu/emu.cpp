@@ -18,10 +18,42 @@ struct EmuBackend {
     if (it == tabs.end()) it = tabs.emplace(k, make()).first;
     return it->second.data();
   }
+  int pf_launches = 0;  // passes that took the prefetching kernel's phases
   void launch_pass(bool inv, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) {
     NttPass pass{p};
     std::vector<u64> lds(ntt_lds_words(p.L));
     const u32 T = NTT_THREADS;
+    if (ntt_pf_slabs_per_wg(p, inv, (u64)wgs * cols * nz)) {
+      // k_ntt_pass_pf thread by thread: every phase for all threads before the next one (= the barriers of the kernel; the two
+      // halves of the wave-local store of the contiguous pass are separated the same way)
+      pf_launches++;
+      const bool strided = ntt_pf_strided(p);
+      const int fmode = !strided || !p.scale_mode ? 0 : (p.sc_step ? 2 : 1);
+      std::vector<u64> regs((size_t)T * 16), twl(NttPass::PF_TW_WORDS_CONTIGUOUS);
+      for (u32 t = 0; t < T; t++) strided ? pass.pf_stage_twiddles<true>(twl.data(), t) : pass.pf_stage_twiddles<false>(twl.data(), t);
+      for (u32 z = p.z_base; z < p.z_base + nz; z++)
+        for (u32 c = 0; c < cols; c++)
+          for (u32 w = 0; w < wgs; w++) {
+            for (u32 t = 0; t < T; t++) pass.prefetch(t, T, w, c, z, &regs[16 * t]);
+            for (u32 t = 0; t < T; t++) {
+              if (!strided) pass.pf_first_step<false, 0>(lds.data(), t, w, z, &regs[16 * t], p.group_tw);
+              else if (fmode == 0) pass.pf_first_step<true, 0>(lds.data(), t, w, z, &regs[16 * t], twl.data());
+              else if (fmode == 1) pass.pf_first_step<true, 1>(lds.data(), t, w, z, &regs[16 * t], twl.data());
+              else pass.pf_first_step<true, 2>(lds.data(), t, w, z, &regs[16 * t], twl.data());
+            }
+            if (strided) {
+              for (u32 t = 0; t < T; t++) pass.pf_mid_step<7>(lds.data(), t, 5, twl.data() + 512);
+              for (u32 t = 0; t < T; t++) pass.pf_last_strided_read(lds.data(), t, &regs[16 * t]);
+              for (u32 t = 0; t < T; t++) pass.pf_last_strided_store(t, w, c, z, &regs[16 * t]);
+            } else {
+              for (u32 t = 0; t < T; t++) pass.pf_mid_step<7>(lds.data(), t, 9, twl.data());
+              for (u32 t = 0; t < T; t++) pass.pf_mid_step<4>(lds.data(), t, 6, twl.data() + 1024);
+              for (u32 t = 0; t < T; t++) pass.pf_last_contiguous(lds.data(), t);
+              for (u32 t = 0; t < T; t++) pass.pf_store_wave_rows(lds.data(), t, w, c, z);
+            }
+          }
+      return;
+    }
     for (u32 z = p.z_base; z < p.z_base + nz; z++)
       for (u32 c = 0; c < cols; c++)
         for (u32 w = 0; w < wgs; w++) {
@@ -73,9 +105,13 @@ u64 emu_gl_shl(u64 x, unsigned s) {
     default: return ~0ull;
   }
 }
-void emu_ntt_forward(const u64 *in, u64 *out, u32 lg, u32 ncols, u64 shift, u32 zbits) {
+// returns the number of passes that ran as the prefetching kernel (k_ntt_pass_pf)
+int emu_ntt_forward(const u64 *in, u64 *out, u32 lg, u32 ncols, u64 shift, u32 zbits) {
   EmuBackend be; NttHost<EmuBackend> h(be);
+  if (zbits & 0x100) { h.computed_scale = true; zbits &= 0xff; }  // test hook: the computed coset scale (FMODE 2)
+  else h.computed_scale = false;
   h.forward(in, (u64)1 << lg, out, (u64)1 << (lg + zbits), lg, ncols, shift, zbits);
+  return be.pf_launches;
 }
 void emu_ntt_inverse_natural(const u64 *in, u64 *out, u32 lg, u32 ncols) {
   EmuBackend be; NttHost<EmuBackend> h(be);

@@ -21,6 +21,7 @@ def load():
     E.emu_gl_mul.argtypes = [c.c_uint64, c.c_uint64]
     E.emu_gl_shl.restype = c.c_uint64
     E.emu_gl_shl.argtypes = [c.c_uint64, c.c_uint]
+    E.emu_ntt_forward.restype = c.c_int
     E.emu_ntt_forward.argtypes = [V, V, c.c_uint32, c.c_uint32, c.c_uint64, c.c_uint32]
     E.emu_ntt_inverse_natural.argtypes = [V, V, c.c_uint32, c.c_uint32]
     E.emu_ntt_inverse_bitrev.argtypes = [V, V, c.c_uint32, c.c_uint32, c.c_uint64]

@@ -88,3 +88,30 @@ def test_emu_ntt_three_pass_plan(oracle, emu):
     oracle.orc_fft(vp(ref), n)
     perm = bitrev_perm(lg)
     assert (out[0] == ref[0][perm]).all()
+
+
+@pytest.mark.parametrize("computed_scale", [False, True])
+def test_emu_lde_headline_shape_takes_the_prefetching_kernel(oracle, emu, computed_scale):
+    """n = 2^22 (the headline size) is the one size whose passes have the shapes of k_ntt_pass_pf (9 strided + 13 contiguous bits):
+    the fused first step on the prefetched registers, the register store of the strided pass, the wave-local store of the contiguous
+    pass, the coset scale from the table and computed (FMODE 1 / 2) - one column of the LDE against the oracle's textbook transform"""
+    lg, n = 22, 1 << 22
+    rng = np.random.default_rng(2200 + computed_scale)
+    x = rand_field(rng, (1, n), canonical=False)
+    lde = np.zeros((1, n * 8), dtype=np.uint64)
+    assert emu.emu_ntt_forward(vp(x), vp(lde), lg, 1, 7, 3 | (0x100 if computed_scale else 0)) == 2  # both passes
+    assert (lde == lde_leaf_order(oracle, x % np.uint64(P))).all()
+
+
+def test_emu_plain_forward_headline_shape(oracle, emu):
+    # the same shapes without a coset scale (FMODE 0): 8 columns are the fewest for which the launch takes the prefetching form
+    lg, n = 22, 1 << 22
+    rng = np.random.default_rng(2222)
+    x = rand_field(rng, (8, n))
+    out = np.zeros_like(x)
+    assert emu.emu_ntt_forward(vp(x), vp(out), lg, 8, 1, 0) == 2
+    perm = bitrev_perm(lg)
+    for c in (0, 5):
+        ref = x[c].copy()
+        oracle.orc_fft(vp(ref), n)
+        assert (out[c] == ref[perm]).all()
