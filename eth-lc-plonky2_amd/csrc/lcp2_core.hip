@@ -235,7 +235,6 @@ static int lde_and_merkle(lcp2_ctx *ctx, lcp2_oracle *o) {
   NttHost<DeviceNttBackend> ntt(be);
   {
     ProfScope ps(ctx, LCP2_K_LDE, (double)o->ncols * (8.0 * n + 8.0 * N));
-    if (getenv("LCP2_NTT_CS")) ntt.computed_scale = true;  // TEMP A/B
     ntt.forward(o->coeffs.u(), n, o->lde.u(), N, o->log_n, o->ncols, GL_GENERATOR, o->rate_bits, o->block_first, o->block_count);
   }
   if (be.status) return be.status;
@@ -351,7 +350,6 @@ extern "C" int lcp2_lde_batch(lcp2_ctx *ctx, const uint64_t *coeffs, uint64_t *o
       for (u64 i = 0; i < N; i++) LCP2_HIP(ctx, hipMemcpyAsync(so.d + c * N + i, si.d + c, sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     ProfScope ps(ctx, LCP2_K_LDE, (double)ncols * (8.0 * n + 8.0 * N));
-    if (getenv("LCP2_NTT_CS")) ntt.computed_scale = true;  // TEMP A/B
     ntt.forward(si.d, n, so.d, N, log_n, (u32)ncols, GL_GENERATOR, rate_bits);
   }
   if (be.status) return be.status;

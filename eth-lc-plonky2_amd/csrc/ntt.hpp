@@ -54,10 +54,10 @@ struct TwoLevelTable {  // value(e) = lo[e & (2^h - 1)] * hi[e >> h];  h = NTT_D
 };
 constexpr u32 NTT_DIRECT = 63;
 constexpr u32 NTT_DIRECT_MAX_LG = 22;
-#ifndef LCP2_NTT_PF_COMPUTED_SCALE
-#define LCP2_NTT_PF_COMPUTED_SCALE 0
-#endif
-constexpr bool NTT_PF_COMPUTED_SCALE = LCP2_NTT_PF_COMPUTED_SCALE;  // coset scale of the prefetching kernel: 0 one-level table, 1 computed (FMODE 2)  // one-level tables up to 2^22 entries (32 MiB) per table row
+// Coset scale of the prefetching kernel: computed from one table value per thread (FMODE 2) or read from the one-level table
+// (FMODE 1).  Measured on MI355X (43 columns of 2^22, rate 8; profiles/r03_lde_ab.md): computed 16.46 ms and 2.4 GB fetched by the
+// first pass, table 16.97 ms and 6.5 GB.
+constexpr bool NTT_PF_COMPUTED_SCALE = true;  // one-level tables up to 2^22 entries (32 MiB) per table row
 
 struct NttPassParams {
   const u64 *in;
@@ -77,6 +77,7 @@ struct NttPassParams {
   u64 scale_scalar;
   TwoLevelTable sc;                   // forward: applied at load; inverse: at store
   u64 sc_lo_z_stride, sc_hi_z_stride;
+  u32 canonical_in;                   // the input is known to be canonical (it is the output of an earlier pass)
   const u64 *sc_step;                 // [z][16]: shift_z^(k * 2^(g_lo + 5)), the ratio between a thread's elements in the fused first step
                                       // of k_ntt_pass_pf (nullptr: the factors come from the one-level table)
 };
@@ -318,7 +319,7 @@ struct NttPass {
         for (u32 j = 1; j < 8; j++) x[j] = gl_mul(v[2 * j + b], stp[2 * j]);
       } else {
 #pragma unroll
-        for (u32 j = 0; j < 8; j++) x[j] = gl_canon(v[2 * j + b]);
+        for (u32 j = 0; j < 8; j++) x[j] = STRIDED ? gl_canon(v[2 * j + b]) : v[2 * j + b];  // contiguous: p.canonical_in (ntt_pf_contiguous)
       }
       ntt_reg_dif<3>(x);
       if (FMODE == 2) {
@@ -539,7 +540,7 @@ struct NttPass {
 // grid still fills the chip.  (Forward passes only: the inverse instantiations need more VGPRs than four waves per SIMD leave.)
 inline bool ntt_pf_strided(const NttPassParams &p) { return p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333; }
 inline bool ntt_pf_contiguous(const NttPassParams &p) {
-  return p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0 && p.scale_mode == 0;
+  return p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0 && p.scale_mode == 0 && p.canonical_in;
 }
 // slabs per workgroup of the prefetching form, 0 = the launch takes the plain kernel.  Only the first load of a workgroup is
 // exposed, so as many as still leave 2048 workgroups (4 rounds of the 512 resident ones) and divide the slab count into a

@@ -193,6 +193,7 @@ struct NttHost {
         // remaining groups: in place over the whole out column (all coset blocks are just more sub-transforms)
         p.in = out; p.in_col_stride = out_col_stride;
         p.out = out; p.out_col_stride = out_col_stride;
+        p.canonical_in = 1;  // written by the pass before
         wgs = 1u << (lg + lgcount - g.L);
         nz = 1;
       }
