@@ -25,7 +25,7 @@ struct lcp2_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string last_error;
-  lcp2::u64 *d_rc = nullptr;  // 360 Poseidon round constants
+  lcp2::u64 *d_rc = nullptr;  // POS_RC_WORDS: the 360 Poseidon round constants + the group constants of the partial rounds
   std::map<std::string, lcp2::u64 *> tables;
   bool prof_on = false;
   lcp2::ProfFamily fam[LCP2_K_COUNT];

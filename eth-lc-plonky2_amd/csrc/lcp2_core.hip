@@ -59,8 +59,9 @@ extern "C" int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LCP2_E_HIP; }
     ctx->own_stream = true;
   }
-  u64 rc[POS_ROUNDS * POS_W];
+  u64 rc[POS_RC_WORDS];  // the 360 round constants, then the group constants of the partial rounds (poseidon.hpp)
   pos_derive_round_constants(rc);
+  pos_extend_round_constants(rc);
   if (hipMalloc((void **)&ctx->d_rc, sizeof rc) != hipSuccess ||
       hipMemcpy(ctx->d_rc, rc, sizeof rc, hipMemcpyHostToDevice) != hipSuccess) {
     lcp2_ctx_destroy(ctx);

@@ -19,6 +19,81 @@ constexpr int POS_FULL_HALF = 4;
 constexpr int POS_PARTIAL = 22;
 constexpr int POS_ROUNDS = 30;
 
+// ---- Partial rounds three at a time --------------------------------------------------------------------------------------
+// In a partial round only element 0 goes through the S-box; elements 1..11 pass through the round linearly.  With u = state after the
+// constant layer, y = u[1..12), w = u[0]^7 and the MDS matrix M cut into m00 = M[0][0], a = M[0][1..], b = M[1..][0], A = M[1..][1..]:
+//     next u0 = a.y + m00 w + c0          next y = A y + b w + c[1..]
+// so three rounds in a row are (w0, w1, w2 the three S-box outputs, u1, u2, u3 the element 0 after each round)
+//     u1 = a.y            + m00 w0                          + k1          w1 = u1^7
+//     u2 = (aA).y         + (a.b) w0   + m00 w1             + k2          w2 = u2^7
+//     u3 = (aA^2).y       + (aAb) w0   + (a.b) w1 + m00 w2  + k3
+//     y3 = A^3 y + A^2 b w0 + A b w1   + b w2               + kv
+// with k1, k2, k3, kv[11] affine images of the three rounds' constants (computed once on the host, pos_extend_round_constants).
+// The entries of A^3 stay below 2^21 (the MDS entries are at most 41; A^4 would overflow the 64-bit accumulators of the 32-bit
+// halves), so every product is still ONE v_mad_u64_u32 per half: 386 of them and 14 folds for three rounds, against 3 x (290 + 12)
+// for three plain MDS layers.  21 of the 22 partial rounds run as 7 such groups: 15.9 k VALU instructions per permutation instead
+// of 20.5 k.  (plonky2's own "fast partial rounds" reach the same end with full 64-bit constants, which cost 17 instructions per
+// product on this ISA and come out even; this form keeps the constants small.)
+constexpr int POS_GROUP = 3;                        // partial rounds per group
+constexpr int POS_GROUPS = POS_PARTIAL / POS_GROUP;  // 7 groups = 21 rounds, the 22nd runs as a plain round
+constexpr int POS_GROUP_CONSTS = 3 + 11;            // k1, k2, k3, kv[11]
+constexpr int POS_RC_WORDS = POS_ROUNDS * POS_W + POS_GROUPS * POS_GROUP_CONSTS;  // the device table: round constants, then the group constants
+
+struct PosPartialTables {
+  u32 m00, ab, aAb;
+  u32 a[11], aA[11], aA2[11], b[11], Ab[11], A2b[11];
+  u32 A[11][11], A3[11][11];
+};
+constexpr PosPartialTables pos_partial_tables() {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  PosPartialTables t{};
+  u64 M[12][12] = {};
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) M[r][c] = C[(c - r + 12) % 12] + (r == 0 && c == 0 ? 8 : 0);
+  u64 A[11][11] = {}, A2[11][11] = {}, A3[11][11] = {}, a[11] = {}, b[11] = {};
+  for (int i = 0; i < 11; i++) {
+    a[i] = M[0][1 + i];
+    b[i] = M[1 + i][0];
+    for (int j = 0; j < 11; j++) A[i][j] = M[1 + i][1 + j];
+  }
+  for (int i = 0; i < 11; i++)
+    for (int j = 0; j < 11; j++) {
+      u64 acc = 0;
+      for (int k = 0; k < 11; k++) acc += A[i][k] * A[k][j];
+      A2[i][j] = acc;
+    }
+  for (int i = 0; i < 11; i++)
+    for (int j = 0; j < 11; j++) {
+      u64 acc = 0;
+      for (int k = 0; k < 11; k++) acc += A2[i][k] * A[k][j];
+      A3[i][j] = acc;
+    }
+  t.m00 = (u32)M[0][0];
+  u64 ab = 0, aAb = 0;
+  for (int i = 0; i < 11; i++) {
+    u64 Ab = 0, A2b = 0, aA = 0, aA2 = 0;
+    for (int k = 0; k < 11; k++) { Ab += A[i][k] * b[k]; A2b += A2[i][k] * b[k]; aA += a[k] * A[k][i]; aA2 += a[k] * A2[k][i]; }
+    t.a[i] = (u32)a[i]; t.b[i] = (u32)b[i]; t.Ab[i] = (u32)Ab; t.A2b[i] = (u32)A2b; t.aA[i] = (u32)aA; t.aA2[i] = (u32)aA2;
+    ab += a[i] * b[i];
+    aAb += a[i] * Ab;
+    for (int j = 0; j < 11; j++) { t.A[i][j] = (u32)A[i][j]; t.A3[i][j] = (u32)A3[i][j]; }
+  }
+  t.ab = (u32)ab; t.aAb = (u32)aAb;
+  return t;
+}
+constexpr u32 pos_partial_max_entry() {
+  constexpr PosPartialTables t = pos_partial_tables();
+  u32 m = t.aAb > t.ab ? t.aAb : t.ab;
+  for (int i = 0; i < 11; i++) {
+    if (t.A2b[i] > m) m = t.A2b[i];
+    if (t.aA2[i] > m) m = t.aA2[i];
+    for (int j = 0; j < 11; j++) if (t.A3[i][j] > m) m = t.A3[i][j];
+  }
+  return m;
+}
+// 14 terms of (32-bit half) x (entry) plus a 32-bit constant half must fit the 64-bit accumulator, and the fold needs sums below 2^59
+static_assert(pos_partial_max_entry() < (1u << 22), "grouped partial rounds: a table entry is too large for one multiply-accumulate per half");
+
 // x^7 on lazy (non-canonical) values: two squarings + two products, no canonicalisation in between
 LCP2_HD u64 pos_sbox(u64 x) {
   u64 x2 = gl_sqr_nc(x);
@@ -84,6 +159,79 @@ LCP2_HD void pos_permute_portable(u64 s[12], const u64 *__restrict__ rc) {
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
+// The group constants of partial rounds r, r+1, r+2 (r = 4 + 3 g), appended to the 360 round constants, with c1 / c2 / c3 the
+// constants of rounds r+1 / r+2 / r+3 (the constant layer of a round rides in the accumulators of the layer before):
+//   k1 = c1[0]   k2 = a.c1[1..] + c2[0]   k3 = a.(A c1[1..] + c2[1..]) + c3[0]   kv = A (A c1[1..] + c2[1..]) + c3[1..]
+inline void pos_extend_round_constants(u64 rc[POS_RC_WORDS]) {
+  constexpr PosPartialTables T = pos_partial_tables();
+  for (int g = 0; g < POS_GROUPS; g++) {
+    const int r = POS_FULL_HALF + POS_GROUP * g;
+    const u64 *c1 = rc + 12 * (r + 1), *c2 = rc + 12 * (r + 2), *c3 = rc + 12 * (r + 3);
+    u64 *k = rc + POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g;
+    u64 v2[11];
+    u64 k2 = c2[0], k3 = c3[0];
+    for (int i = 0; i < 11; i++) {
+      u64 acc = c2[1 + i];
+      for (int j = 0; j < 11; j++) acc = gl_add(acc, gl_mul(T.A[i][j], c1[1 + j]));
+      v2[i] = acc;
+      k2 = gl_add(k2, gl_mul(T.a[i], c1[1 + i]));
+    }
+    for (int i = 0; i < 11; i++) {
+      u64 acc = c3[1 + i];
+      for (int j = 0; j < 11; j++) acc = gl_add(acc, gl_mul(T.A[i][j], v2[j]));
+      k[3 + i] = acc;
+      k3 = gl_add(k3, gl_mul(T.a[i], v2[i]));
+    }
+    k[0] = c1[0]; k[1] = k2; k[2] = k3;
+  }
+}
+
+// The grouped form in portable arithmetic (what the gfx950 form computes, on canonical values): tests/emu checks it against the
+// plain definition above and the oracle.  rc: POS_RC_WORDS words (pos_derive_round_constants + pos_extend_round_constants).
+LCP2_HD void pos_permute_grouped_portable(u64 s[12], const u64 *__restrict__ rc) {
+  constexpr PosPartialTables T = pos_partial_tables();
+  for (int i = 0; i < 12; i++) s[i] = gl_add(gl_canon(s[i]), rc[i]);
+  int round = 0;
+  for (int r = 0; r < POS_FULL_HALF; r++, round++) {
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(pos_sbox(s[i]));
+    pos_mds(s);
+    for (int i = 0; i < 12; i++) s[i] = gl_add(gl_canon(s[i]), rc[(round + 1) * 12 + i]);
+  }
+  for (int g = 0; g < POS_GROUPS; g++, round += POS_GROUP) {
+    const u64 *k = rc + POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g;
+    const u64 *y = s + 1;
+    const u64 w0 = gl_canon(pos_sbox(s[0]));
+    u64 u1 = gl_add(k[0], gl_mul(T.m00, w0)), u2 = gl_add(k[1], gl_mul(T.ab, w0)), u3 = gl_add(k[2], gl_mul(T.aAb, w0));
+    for (int j = 0; j < 11; j++) {
+      u1 = gl_add(u1, gl_mul(T.a[j], y[j]));
+      u2 = gl_add(u2, gl_mul(T.aA[j], y[j]));
+      u3 = gl_add(u3, gl_mul(T.aA2[j], y[j]));
+    }
+    const u64 w1 = gl_canon(pos_sbox(u1));
+    u2 = gl_add(u2, gl_mul(T.m00, w1));
+    const u64 w2 = gl_canon(pos_sbox(u2));
+    u3 = gl_add(gl_add(u3, gl_mul(T.ab, w1)), gl_mul(T.m00, w2));
+    u64 ny[11];
+    for (int i = 0; i < 11; i++) {
+      u64 acc = gl_add(k[3 + i], gl_add(gl_mul(T.A2b[i], w0), gl_add(gl_mul(T.Ab[i], w1), gl_mul(T.b[i], w2))));
+      for (int j = 0; j < 11; j++) acc = gl_add(acc, gl_mul(T.A3[i][j], y[j]));
+      ny[i] = acc;
+    }
+    s[0] = u3;
+    for (int i = 0; i < 11; i++) s[1 + i] = ny[i];
+  }
+  for (; round < POS_FULL_HALF + POS_PARTIAL; round++) {  // the partial round the groups leave over
+    s[0] = gl_canon(pos_sbox(s[0]));
+    pos_mds(s);
+    for (int i = 0; i < 12; i++) s[i] = gl_add(gl_canon(s[i]), rc[(round + 1) * 12 + i]);
+  }
+  for (int r = 0; r < POS_FULL_HALF; r++, round++) {
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(pos_sbox(s[i]));
+    pos_mds(s);
+    for (int i = 0; i < 12; i++) s[i] = round + 1 < POS_ROUNDS ? gl_add(gl_canon(s[i]), rc[(round + 1) * 12 + i]) : gl_canon(s[i]);
+  }
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---------------------------------------------------------------------------------------------------------
 // gfx950 form.  Measured (tools/ubench): VOP3 integer ops ~4.4 cycles per wave-instruction, VOP2 (add/sub with
@@ -146,6 +294,58 @@ __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__r
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
 }
 
+// Three partial rounds (see the tables above): state = u after the constant layer of the first of them, on return u of the round
+// after the third.  kc: the group's 14 constants.
+__device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ kc, const PosK k) {
+  constexpr PosPartialTables T = pos_partial_tables();
+  u32 w0l = lo[0], w0h = hi[0], w1l, w1h, w2l, w2h;
+  pos_sbox_h(w0l, w0h, k);
+  {
+    const u64 c = kc[0];
+    u64 al = (u32)c, ah = c >> 32;
+#pragma unroll
+    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.a[j]; ah += (u64)hi[1 + j] * T.a[j]; }
+    al += (u64)w0l * T.m00; ah += (u64)w0h * T.m00;
+    pos_fold_h(al, ah, w1l, w1h, k);
+    pos_sbox_h(w1l, w1h, k);
+  }
+  {
+    const u64 c = kc[1];
+    u64 al = (u32)c, ah = c >> 32;
+#pragma unroll
+    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA[j]; ah += (u64)hi[1 + j] * T.aA[j]; }
+    al += (u64)w0l * T.ab; ah += (u64)w0h * T.ab;
+    al += (u64)w1l * T.m00; ah += (u64)w1h * T.m00;
+    pos_fold_h(al, ah, w2l, w2h, k);
+    pos_sbox_h(w2l, w2h, k);
+  }
+  u32 nl[12], nh[12];
+  {
+    const u64 c = kc[2];
+    u64 al = (u32)c, ah = c >> 32;
+#pragma unroll
+    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA2[j]; ah += (u64)hi[1 + j] * T.aA2[j]; }
+    al += (u64)w0l * T.aAb; ah += (u64)w0h * T.aAb;
+    al += (u64)w1l * T.ab; ah += (u64)w1h * T.ab;
+    al += (u64)w2l * T.m00; ah += (u64)w2h * T.m00;
+    pos_fold_h(al, ah, nl[0], nh[0], k);
+  }
+#pragma unroll
+  for (int i = 0; i < 11; i++) {
+    const u64 c = kc[3 + i];
+    u64 al = (u32)c, ah = c >> 32;
+#pragma unroll
+    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.A3[i][j]; ah += (u64)hi[1 + j] * T.A3[i][j]; }
+    al += (u64)w0l * T.A2b[i]; ah += (u64)w0h * T.A2b[i];
+    al += (u64)w1l * T.Ab[i]; ah += (u64)w1h * T.Ab[i];
+    al += (u64)w2l * T.b[i]; ah += (u64)w2h * T.b[i];
+    pos_fold_h(al, ah, nl[1 + i], nh[1 + i], k);
+  }
+#pragma unroll
+  for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
+}
+
+// rc: POS_RC_WORDS words (the 360 round constants, then the group constants of the partial rounds)
 __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restrict__ rc) {
   const PosK k = pos_consts();
   u32 lo[12], hi[12];
@@ -159,7 +359,9 @@ __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restr
     pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
   }
 #pragma unroll 1
-  for (int r = 0; r < POS_PARTIAL; r++, round++) {
+  for (int g = 0; g < POS_GROUPS; g++, round += POS_GROUP) pos_partial3_h(lo, hi, rc + POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g, k);
+#pragma unroll 1
+  for (; round < POS_FULL_HALF + POS_PARTIAL; round++) {
     pos_sbox_h(lo[0], hi[0], k);
     pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
   }

@@ -77,12 +77,22 @@ struct EmuBackend {
   }
 };
 
-static u64 g_rc[360];
+static u64 g_rc[POS_RC_WORDS];
 static bool g_rc_ok = false;
+static void rc_init() {
+  if (!g_rc_ok) { pos_derive_round_constants(g_rc); pos_extend_round_constants(g_rc); g_rc_ok = true; }
+}
 
 extern "C" {
+// the partial rounds three at a time (what the gfx950 form of the permutation computes), in portable arithmetic
+void emu_poseidon_permute_grouped(u64 *s) {
+  rc_init();
+  pos_permute_grouped_portable(s, g_rc);
+}
+// the largest entry of the constant tables of the grouped partial rounds
+u32 emu_poseidon_partial_max_entry() { return pos_partial_max_entry(); }
 void emu_poseidon_permute(u64 *s) {
-  if (!g_rc_ok) { pos_derive_round_constants(g_rc); g_rc_ok = true; }
+  rc_init();
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
   pos_permute(s, g_rc);
 }

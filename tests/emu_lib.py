@@ -17,6 +17,8 @@ def load():
     c = ctypes
     V = c.c_void_p
     E.emu_poseidon_permute.argtypes = [V]
+    E.emu_poseidon_permute_grouped.argtypes = [V]
+    E.emu_poseidon_partial_max_entry.restype = c.c_uint32
     E.emu_gl_mul.restype = c.c_uint64
     E.emu_gl_mul.argtypes = [c.c_uint64, c.c_uint64]
     E.emu_gl_shl.restype = c.c_uint64

@@ -2,7 +2,7 @@
 """Instruction census of one Poseidon permutation as compiled into liblcp2.so, weighted by the issue rates measured with
 tools/ubench/int_rates (profiles/r02_ubench_int_rates.txt): the opcode-weighted issue floor of the hash kernels.
 
-The permutation inside k_poseidon_permute_batch is three rolled loops (4 full rounds, 22 partial rounds, 3 full rounds) and an
+The permutation inside k_poseidon_permute_batch is three rolled loops (4 full rounds, 7 groups of three partial rounds, 3 full rounds), one peeled partial round and an
 unrolled last round; the loops are found as backward s_cbranch edges and their bodies are multiplied by the trip counts.
     python tools/poseidon_census.py [liblcp2.so] > profiles/r02_poseidon_census.json"""
 import json
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_hazards as ch  # noqa: E402
 
-TRIPS = [4, 22, 3]  # POS_FULL_HALF, POS_PARTIAL, POS_FULL_HALF - 1 (the last full round is peeled)
+TRIPS = [4, 7, 3]  # POS_FULL_HALF, POS_GROUPS (three partial rounds per trip; the 22nd partial round is peeled), POS_FULL_HALF - 1 (the last full round is peeled)
 INSN = re.compile(r"^\s+([a-z][a-z0-9_]*)\s*(.*?)\s*//\s*([0-9A-F]+):")
 
 
