@@ -359,19 +359,36 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
     for (int j = 0; j < 12; j++) nxt[j] = rc[(round + 1) * 12 + j];
     pos_mds_h(lo, hi, nxt, k);
   }
-  // partial rounds: the 22 S-box wires are fetched in groups of QUOTIENT_STAGE through the staging slots (LDS)
-#pragma unroll 1
-  for (u32 r = 0; r < POS_PARTIAL; r++, round++) {
-    if (r % QUOTIENT_STAGE == 0) {
-      u64 pw[QUOTIENT_STAGE];
+  // partial rounds, three at a time as in the hash kernels (poseidon.hpp pos_partial3_core): element 0 after every round is
+  // emitted against the gate's S-box wire and the round continues from the wire.  The 22 S-box wires are fetched in groups of
+  // QUOTIENT_STAGE through the staging slots (LDS; this kernel has no interpreter registers).
+  static_assert(QUOTIENT_STAGE % POS_GROUP == 0, "a group of partial rounds must not straddle two staging batches");
+  auto stage_sbox_wires = [&](u32 r) {
+    u64 pw[QUOTIENT_STAGE];
 #pragma unroll
-      for (u32 j = 0; j < QUOTIENT_STAGE; j++) pw[j] = W[(u64)(65 + min(r + j, (u32)POS_PARTIAL - 1)) * st];
+    for (u32 j = 0; j < QUOTIENT_STAGE; j++) pw[j] = W[(u64)(65 + min(r + j, (u32)POS_PARTIAL - 1)) * st];
 #pragma unroll
-      for (u32 j = 0; j < QUOTIENT_STAGE; j++) lds[j * T + tid] = pw[j];  // slots [0, QUOTIENT_STAGE): this kernel has no interpreter registers
-    }
+    for (u32 j = 0; j < QUOTIENT_STAGE; j++) lds[j * T + tid] = pw[j];
+  };
+  auto constrain0 = [&](u32 r, u32 &ul, u32 &uh) {  // element 0 - S-box wire of partial round r; element 0 <- the wire
     const u64 w = lds[(r % QUOTIENT_STAGE) * T + tid];
-    emit(gl_sub(gl_canon(((u64)hi[0] << 32) | lo[0]), w));
-    lo[0] = (u32)w; hi[0] = (u32)(w >> 32);
+    emit(gl_sub(gl_canon(((u64)uh << 32) | ul), w));
+    ul = (u32)w; uh = (u32)(w >> 32);
+  };
+  u32 r = 0;
+#pragma unroll 1
+  for (u32 g = 0; g < POS_GROUPS; g++, r += POS_GROUP, round += POS_GROUP) {
+    if (r % QUOTIENT_STAGE == 0) stage_sbox_wires(r);
+    constrain0(r, lo[0], hi[0]);
+    pos_partial3_core(lo, hi, &rc[POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g], k, [&](int i, u32 &ul, u32 &uh) {
+      constrain0(r + i, ul, uh);
+      pos_sbox_h(ul, uh, k);
+    });
+  }
+#pragma unroll 1
+  for (; r < POS_PARTIAL; r++, round++) {  // the round the groups leave over
+    if (r % QUOTIENT_STAGE == 0) stage_sbox_wires(r);
+    constrain0(r, lo[0], hi[0]);
     pos_sbox_h(lo[0], hi[0], k);
     u64 nxt[12];
 #pragma unroll

@@ -295,8 +295,11 @@ __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__r
 }
 
 // Three partial rounds (see the tables above): state = u after the constant layer of the first of them, on return u of the round
-// after the third.  kc: the group's 14 constants.
-__device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ kc, const PosK k) {
+// after the third.  kc: the group's 14 constants.  next_w(i, ul, uh): element 0 after round i (1, 2) comes in as lazy halves and
+// leaves as the S-box output that enters the following round - the permutation raises it to the 7th power, the PoseidonGate
+// evaluator of the quotient (kernels_prover.hip) emits its difference to the gate's S-box wire and continues from the wire.
+template <class Consts /* pointer to the 14 constants, any address space */, class NextW>
+__device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts kc, const PosK k, NextW next_w) {
   constexpr PosPartialTables T = pos_partial_tables();
   u32 w0l = lo[0], w0h = hi[0], w1l, w1h, w2l, w2h;
   pos_sbox_h(w0l, w0h, k);
@@ -307,7 +310,7 @@ __device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.a[j]; ah += (u64)hi[1 + j] * T.a[j]; }
     al += (u64)w0l * T.m00; ah += (u64)w0h * T.m00;
     pos_fold_h(al, ah, w1l, w1h, k);
-    pos_sbox_h(w1l, w1h, k);
+    next_w(1, w1l, w1h);
   }
   {
     const u64 c = kc[1];
@@ -317,7 +320,7 @@ __device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64
     al += (u64)w0l * T.ab; ah += (u64)w0h * T.ab;
     al += (u64)w1l * T.m00; ah += (u64)w1h * T.m00;
     pos_fold_h(al, ah, w2l, w2h, k);
-    pos_sbox_h(w2l, w2h, k);
+    next_w(2, w2l, w2h);
   }
   u32 nl[12], nh[12];
   {
@@ -343,6 +346,9 @@ __device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
+}
+__device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ kc, const PosK k) {
+  pos_partial3_core(lo, hi, kc, k, [&](int, u32 &ul, u32 &uh) { pos_sbox_h(ul, uh, k); });
 }
 
 // rc: POS_RC_WORDS words (the 360 round constants, then the group constants of the partial rounds)
