@@ -40,29 +40,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a full-rate wave64 VALU instruction issues in 2 cycles, 2.4 GHz -> 78.6 T lane-instructions/s
 VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9
 CLOCK_HZ = 2.4e9
-CENSUS = os.path.join(ROOT, "profiles", "r02_poseidon_census.json")  # tools/poseidon_census.py: instructions per permutation by
-# issue class x the issue rate of each class measured alone (tools/ubench/int_rates -> profiles/r02_ubench_int_rates.txt)
+CENSUS = os.path.join(ROOT, "profiles", "r03_poseidon_census.json")  # tools/poseidon_census.py: VALU instructions per permutation as compiled
 
 
 def valu_roofline(perms_per_s):
-    """Poseidon is integer-VALU bound.  Two honest denominators: the full-rate VALU peak of the guide (every instruction at 2
-    cycles: unreachable for this opcode mix, v_mad_u64_u32 and the carry ops issue at 4.2-4.4), and the opcode-weighted issue floor
-    (each class at the rate it reaches alone in the microbenchmark).  No fraction above 1 is printed: where the kernel's mixed
-    stream issues faster than the solo rates predict, the fraction is 1 and `floor_exceeded_by` carries the ratio."""
+    """Poseidon is integer-VALU bound.  One denominator: the full-rate VALU peak of the guide (every wave64 instruction at 2 cycles,
+    78.6 T lane-instructions/s).  No stream of 64-bit integer multiplies can reach it on this ISA - v_mad_u64_u32 and the carry ops
+    issue at 4.2-4.4 cycles alone (profiles/r02_ubench_int_rates.txt) - so the fraction is a lower bound on how busy the VALU is; the
+    measured cycles per instruction say the rest.  (Round 2 also printed a fraction of a "solo-class issue floor"; the kernel beat that
+    floor by 9 %, so it was a mis-model and is gone.)"""
     try:
-        c = json.load(open(CENSUS))
-        instr, floor_cycles = c["valu_instructions"], c["issue_floor_cycles_per_permutation_per_wave"]
+        instr = json.load(open(CENSUS))["valu_instructions"]
     except (OSError, KeyError, ValueError):
         return {"permutations_per_s": perms_per_s}
     lane_instr = perms_per_s * instr
-    floor_perms = 256 * 4 * 64 * CLOCK_HZ / floor_cycles  # every SIMD issuing back to back, 64 permutations per wave
-    ratio = perms_per_s / floor_perms
     return {"permutations_per_s": perms_per_s, "valu_instructions_per_permutation": instr,
             "achieved_lane_instr_per_s": lane_instr, "full_rate_peak_lane_instr_per_s": VALU_PEAK_LANE_INSTR,
             "frac_of_full_rate_peak": lane_instr / VALU_PEAK_LANE_INSTR,
-            "issue_floor_permutations_per_s": floor_perms, "frac_of_issue_floor": min(ratio, 1.0),
-            "floor_exceeded_by": ratio if ratio > 1.0 else None,
             "cycles_per_valu_instruction_per_simd": 256 * 4 * 64 * CLOCK_HZ / lane_instr}
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench (tools/collect_profiles.sh)
 
