@@ -92,7 +92,8 @@ void launch_hash_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 ari
 void launch_merkle_level(hipStream_t s, const u64 *children, u64 *parents, u64 nparents, const u64 *rc);
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz);
 void launch_bitrev_tile(hipStream_t s, const BitrevTile &b, u32 wgs, u32 cols);
-void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols);
+void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols, unsigned long long *noncanonical = nullptr);
+void launch_canon_copy(hipStream_t s, const u64 *in, u64 *out /* nullable: scan only */, u64 count, unsigned long long *noncanonical);
 void launch_sha256_level(hipStream_t s, const uint8_t *children, uint8_t *parents, u64 nparents_per_tree, u64 trees,
                          u64 child_tree_stride, u64 parent_tree_stride, uint32_t *trace, u64 trace_tree_stride,
                          u64 trace_hash_offset);
@@ -113,8 +114,8 @@ struct DeviceNttBackend {
   const u64 *table(const std::string &key, std::function<std::vector<u64>()> make);
   void launch_pass(bool inv, const NttPassParams &p, u32 wgs, u32 cols, u32 nz) { launch_ntt_pass(ctx->stream, inv, p, wgs, cols, nz); }
   void launch_bitrev(const BitrevTile &b, u32 wgs, u32 cols) { launch_bitrev_tile(ctx->stream, b, wgs, cols); }
-  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
-    lcp2::launch_bitrev_small(ctx->stream, in, is, out, os, lg, cols);
+  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols, unsigned long long *noncanonical = nullptr) {
+    lcp2::launch_bitrev_small(ctx->stream, in, is, out, os, lg, cols, noncanonical);
   }
 };
 
@@ -143,8 +144,11 @@ struct lcp2_oracle {
 
 namespace lcp2 {
 // internal commitment builders on device-resident input
+// shape checks shared by build(), the verifier-only constructor and every entry point that computes a proof layout: nullptr or
+// the reason; *unsupported tells LCP2_E_UNSUPPORTED from LCP2_E_INVALID (prover.hip)
+const char *params_problem(const lcp2_params &p, bool *unsupported);
 int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t log_n, uint32_t rate_bits,
-                      uint32_t cap_height, lcp2_oracle *o);
+                      uint32_t cap_height, lcp2_oracle *o, unsigned long long *noncanonical = nullptr /* device word, set to 1 if a value is >= p */);
 int commit_coeffs_dev(lcp2_ctx *ctx, const u64 *d_coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                       uint32_t cap_height, lcp2_oracle *o, bool take_copy);
 int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o);

@@ -119,11 +119,24 @@ __global__ __launch_bounds__(256) void k_bitrev_tile(BitrevTile b) {
   b.store(lds, threadIdx.x, 256, blockIdx.x, blockIdx.y);
 }
 
-__global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restrict__ out, u64 os, u32 lg) {
+__global__ void k_bitrev_small(const u64 *__restrict__ in, u64 is, u64 *__restrict__ out, u64 os, u32 lg, unsigned long long *noncanonical) {
   u32 col = blockIdx.y;
   u32 n = 1u << lg;
-  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    out[(u64)col * os + bitrev32(i, lg)] = gl_canon(in[(u64)col * is + i]);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const u64 v = in[(u64)col * is + i];
+    if (noncanonical && v >= GL_P) *noncanonical = 1;
+    out[(u64)col * os + bitrev32(i, lg)] = gl_canon(v);
+  }
+}
+// out = canonical copy of in; the flag as above (witness buffers that do not pass through the bit-reversal of an iNTT)
+__global__ void k_canon_copy(const u64 *in, u64 *out /* may be in */, u64 count, unsigned long long *noncanonical) {
+  bool seen = false;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (u64)gridDim.x * blockDim.x) {
+    const u64 v = in[i];
+    seen = seen || v >= GL_P;
+    if (out) out[i] = gl_canon(v);
+  }
+  if (seen && noncanonical) *noncanonical = 1;
 }
 
 
@@ -152,10 +165,14 @@ void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wg
 void launch_bitrev_tile(hipStream_t s, const BitrevTile &b, u32 wgs, u32 cols) {
   hipLaunchKernelGGL(k_bitrev_tile, dim3(wgs, cols), dim3(256), 0, s, b);
 }
-void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
+void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols, unsigned long long *noncanonical) {
   u32 n = 1u << lg;
   u32 blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_bitrev_small, dim3(blocks, cols), dim3(256), 0, s, in, is, out, os, lg);
+  hipLaunchKernelGGL(k_bitrev_small, dim3(blocks, cols), dim3(256), 0, s, in, is, out, os, lg, noncanonical);
+}
+void launch_canon_copy(hipStream_t s, const u64 *in, u64 *out, u64 count, unsigned long long *noncanonical) {
+  const u64 want = (count + 255) / 256;
+  hipLaunchKernelGGL(k_canon_copy, dim3((unsigned)(want < 8192 ? (want ? want : 1) : 8192)), dim3(256), 0, s, in, out, count, noncanonical);
 }
 
 }  // namespace lcp2

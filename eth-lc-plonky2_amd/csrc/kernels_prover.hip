@@ -429,7 +429,7 @@ __device__ __forceinline__ void q_arithmetic_native(const QuotientArgs &a, u64 i
     for (int k = 3; k >= 0; k--) {
       if (first + k < top) {
         const u64 comp = gl_add(gl_mul(gl_mul(w[4 * k], w[4 * k + 1]), c0), gl_mul(w[4 * k + 2], c1));
-        emit(gl_sub(w[4 * k + 3], comp));
+        emit.horner(gl_sub(w[4 * k + 3], comp));  // listed last to first: plain Horner with alpha (alpha = 0 keeps the LAST one, c_0)
       }
     }
   }
@@ -447,12 +447,12 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       if (top - 1 - j >= 0) {
-        emit(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        emit.horner(gl_sub(gl_mul(w[j], w[j]), w[j]));
         sum = gl_add(gl_add(sum, sum), w[j]);
       }
     }
   }
-  emit(gl_sub(sum, W[0]));
+  emit.horner(gl_sub(sum, W[0]));
 }
 #endif
 
@@ -704,20 +704,20 @@ __device__ __forceinline__ void q_arith_base_pair(const QuotientArgs &a, u64 i, 
     for (int kk = 3; kk >= 0; kk--) {
       if ((hi - 16) / 4 + kk < num_ops) {
         const u64 comp = gl_add(gl_mul(gl_mul(w[4 * kk], w[4 * kk + 1]), c0), gl_mul(w[4 * kk + 2], c1));
-        eA(gl_sub(w[4 * kk + 3], comp));
+        eA.horner(gl_sub(w[4 * kk + 3], comp));
       }
     }
 #pragma unroll
     for (int j = 15; j >= 0; j--) {
       const int limb = hi - 16 + j - 1;  // wire 0 is the sum, limb l sits on wire l + 1
       if (limb >= 0 && limb < num_limbs) {
-        eB(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        eB.horner(gl_sub(gl_mul(w[j], w[j]), w[j]));
         sum = gl_add(gl_add(sum, sum), w[j]);
       }
     }
     if (hi == 16) w0 = w[0];
   }
-  eB(gl_sub(sum, w0));
+  eB.horner(gl_sub(sum, w0));
   const u64 fA = q_filter(a, GA, i), fB = q_filter(a, GB, i);
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)

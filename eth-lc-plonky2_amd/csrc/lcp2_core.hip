@@ -244,7 +244,7 @@ static int lde_and_merkle(lcp2_ctx *ctx, lcp2_oracle *o) {
 }
 
 int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
-                      lcp2_oracle *o) {
+                      lcp2_oracle *o, unsigned long long *noncanonical) {
   if (cap_height > log_n + rate_bits || ncols == 0 || ncols > 65535) return ctx->fail(LCP2_E_INVALID, "commit: bad shape");
   o->ctx = ctx; o->ncols = (uint32_t)ncols; o->log_n = log_n; o->rate_bits = rate_bits; o->cap_height = cap_height;
   const u64 n = (u64)1 << log_n;
@@ -253,7 +253,7 @@ int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t l
   NttHost<DeviceNttBackend> ntt(be);
   {
     ProfScope ps(ctx, LCP2_K_INTT, 16.0 * n * ncols);
-    ntt.inverse_natural(d_vals, n, o->coeffs.u(), n, log_n, (u32)ncols);
+    ntt.inverse_natural(d_vals, n, o->coeffs.u(), n, log_n, (u32)ncols, noncanonical);
   }
   if (be.status) return be.status;
   LCP2_HIP(ctx, hipGetLastError());

@@ -608,13 +608,19 @@ struct BitrevTile {
   u64 *out;
   u64 in_col_stride, out_col_stride;
   u32 lg;
+  unsigned long long *noncanonical;  // nullable: set to 1 when an input value is >= p (the caller's buffer is then not usable as is
+                                     // where canonical values are assumed: the witness check of lcp2_prove)
   LCP2_HD void load(u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col) const {
     const u64 *src = in + (u64)col * in_col_stride;
+    bool seen = false;
     for (u32 i = tid; i < 4096; i += nthr) {
       u32 h = i >> 6, l = i & 63;
       u64 g = ((u64)h << (lg - 6)) | ((u64)wg << 6) | l;
-      lds[h * 65 + l] = gl_canon(src[g]);
+      const u64 v = src[g];
+      seen = seen || v >= GL_P;
+      lds[h * 65 + l] = gl_canon(v);
     }
+    if (seen && noncanonical) *noncanonical = 1;  // every writer stores the same value
   }
   LCP2_HD void store(const u64 *lds, u32 tid, u32 nthr, u32 wg, u32 col) const {
     u64 *dst = out + (u64)col * out_col_stride;

@@ -5,7 +5,7 @@
 //   const u64* Backend::table(const std::string& key, std::function<std::vector<u64>()> make)
 //   void Backend::launch_pass(bool inverse, const NttPassParams&, u32 wgs, u32 cols, u32 z)
 //   void Backend::launch_bitrev(const BitrevTile&, u32 wgs, u32 cols)      (lg >= 12)
-//   void Backend::launch_bitrev_small(in, out, strides, lg, cols)          (lg < 12)
+//   void Backend::launch_bitrev_small(in, out, strides, lg, cols, noncanonical flag)   (lg < 12)
 #pragma once
 #include <functional>
 #include <string>
@@ -228,12 +228,13 @@ struct NttHost {
 
   // ifft of natural-order values -> natural-order coefficients (PolynomialValues::ifft):
   // bit-reversal permutation into `out`, then the in-place inverse passes.
-  void inverse_natural(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols) {
+  // noncanonical (nullable, device word): set to 1 if an input value is >= p
+  void inverse_natural(const u64 *in, u64 in_col_stride, u64 *out, u64 out_col_stride, u32 lg, u32 ncols, unsigned long long *noncanonical = nullptr) {
     if (lg >= 12) {
-      BitrevTile b{in, out, in_col_stride, out_col_stride, lg};
+      BitrevTile b{in, out, in_col_stride, out_col_stride, lg, noncanonical};
       be.launch_bitrev(b, 1u << (lg - 12), ncols);
     } else {
-      be.launch_bitrev_small(in, in_col_stride, out, out_col_stride, lg, ncols);
+      be.launch_bitrev_small(in, in_col_stride, out, out_col_stride, lg, ncols, noncanonical);
     }
     inverse_bitrev_in(out, out_col_stride, out, out_col_stride, lg, ncols, 1);
   }

@@ -58,15 +58,7 @@ struct lcp2_circuit {
   uint32_t nblocks() const { return bc ? bc : (1u << p.rate_bits); }
 };
 
-namespace {
-#define LCP2_TRY(expr) do { int rc_ = (expr); if (rc_ != LCP2_OK) return rc_; } while (0)
-
-// word offsets inside lcp2_circuit::small (per-proof scalars on the device)
-constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
-                 SMALL_CHECK = 21, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
-
-inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
-
+namespace lcp2 {
 // shape checks shared by build() and the verifier-only constructor: everything the prover's workspaces and the verifier's
 // fixed-size arrays rely on.  Returns nullptr or the reason; *unsupported says which status it is.
 const char *params_problem(const lcp2_params &p, bool *unsupported) {
@@ -90,6 +82,17 @@ const char *params_problem(const lcp2_params &p, bool *unsupported) {
   }
   return nullptr;
 }
+}  // namespace lcp2
+
+namespace {
+#define LCP2_TRY(expr) do { int rc_ = (expr); if (rc_ != LCP2_OK) return rc_; } while (0)
+
+// word offsets inside lcp2_circuit::small (per-proof scalars on the device)
+constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
+                 SMALL_CHECK = 21, SMALL_NONCANON = 22, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
+
+inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
+
 int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
   bool unsupported;
   if (const char *why = params_problem(p, &unsupported)) return ctx->fail(unsupported ? LCP2_E_UNSUPPORTED : LCP2_E_INVALID, why);
@@ -206,30 +209,34 @@ static int check_native_gates(lcp2_circuit *c) {
   std::vector<u64> hw((size_t)p.num_wires * cnt), hc((size_t)p.num_constants * cnt), hs(SMALL_GATE_SCALE + (size_t)QUOTIENT_MAX_CH * c->gates.size(), 0);
   for (auto &v : hw) v = rnd();
   for (auto &v : hc) v = rnd();
-  for (u32 k = 0; k < p.num_challenges; k++) {
-    const u64 al = rnd() | 1;
-    hs[SMALL_ALPHAS + k] = gl_canon(al);
-    hs[SMALL_ALPHA_INV + k] = gl_inv(gl_canon(al));
-    for (size_t g = 0; g < c->gates.size(); g++)
-      hs[SMALL_GATE_SCALE + g * QUOTIENT_MAX_CH + k] = c->gates[g].num_constraints ? gl_pow(gl_canon(al), c->gates[g].num_constraints - 1) : 1;
-  }
   for (u32 i = 0; i < 4; i++) hs[SMALL_PI_HASH + i] = rnd();
-  hs[SMALL_CHECK] = ~0ull;
   DevBuf dw, dc;
   LCP2_TRY(upload(ctx, dw, hw.data(), hw.size() * 8));
   LCP2_TRY(upload(ctx, dc, hc.data(), hc.size() * 8));
-  LCP2_HIP(ctx, hipMemcpyAsync(c->small.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  QuotientArgs a{};
-  u64 *d_small = c->small.u();
-  a.wires = dw.u(); a.consts = dc.u(); a.stride = cnt; a.count = cnt;
-  a.alphas = d_small + SMALL_ALPHAS; a.alpha_inv = d_small + SMALL_ALPHA_INV; a.pis = d_small + SMALL_PI_HASH; a.gate_scale = d_small + SMALL_GATE_SCALE;
-  a.imm = c->d_imm.u(); a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.stage_list = (const u32 *)c->d_stage.p;
-  a.num_wires = p.num_wires; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors; a.num_constants = p.num_constants;
-  a.num_challenges = p.num_challenges; a.num_regs = c->num_regs; a.rc = ctx->d_rc;
-  launch_native_check(ctx->stream, a, c->dev_gates, (unsigned long long *)(d_small + SMALL_CHECK));
-  LCP2_HIP(ctx, hipGetLastError());
-  u64 bad = 0;
-  LCP2_TRY(download(ctx, &bad, d_small + SMALL_CHECK, 8));
+  u64 bad = ~0ull;
+  // two settings of the challenges: random ones, and alpha = 0 (there the combination is the FIRST constraint alone, the corner in
+  // which a forward and a last-to-first evaluator differ if one of them folds in the wrong direction)
+  for (int zero_alpha = 0; zero_alpha < 2 && bad == ~0ull; zero_alpha++) {
+    for (u32 k = 0; k < p.num_challenges; k++) {
+      const u64 al = zero_alpha ? 0 : gl_canon(rnd() | 1);
+      hs[SMALL_ALPHAS + k] = al;
+      hs[SMALL_ALPHA_INV + k] = al ? gl_inv(al) : 0;
+      for (size_t g = 0; g < c->gates.size(); g++)
+        hs[SMALL_GATE_SCALE + g * QUOTIENT_MAX_CH + k] = c->gates[g].num_constraints ? gl_pow(al, c->gates[g].num_constraints - 1) : 1;
+    }
+    hs[SMALL_CHECK] = ~0ull;
+    LCP2_HIP(ctx, hipMemcpyAsync(c->small.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    QuotientArgs a{};
+    u64 *d_small = c->small.u();
+    a.wires = dw.u(); a.consts = dc.u(); a.stride = cnt; a.count = cnt;
+    a.alphas = d_small + SMALL_ALPHAS; a.alpha_inv = d_small + SMALL_ALPHA_INV; a.pis = d_small + SMALL_PI_HASH; a.gate_scale = d_small + SMALL_GATE_SCALE;
+    a.imm = c->d_imm.u(); a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.stage_list = (const u32 *)c->d_stage.p;
+    a.num_wires = p.num_wires; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors; a.num_constants = p.num_constants;
+    a.num_challenges = p.num_challenges; a.num_regs = c->num_regs; a.rc = ctx->d_rc;
+    launch_native_check(ctx->stream, a, c->dev_gates, (unsigned long long *)(d_small + SMALL_CHECK));
+    LCP2_HIP(ctx, hipGetLastError());
+    LCP2_TRY(download(ctx, &bad, d_small + SMALL_CHECK, 8));
+  }
   if (bad != ~0ull) return ctx->fail(LCP2_E_INVALID, "a gate flagged LCP2_GATE_NATIVE_* does not compute what its program computes");
   return LCP2_OK;
 }
@@ -418,7 +425,8 @@ extern "C" int lcp2_circuit_digest(const lcp2_circuit *c, uint64_t digest[4], ui
   return LCP2_OK;
 }
 extern "C" size_t lcp2_proof_words(const lcp2_params *p) {
-  if (!p) return 0;
+  bool unsupported;
+  if (!p || params_problem(*p, &unsupported)) return 0;  // the layout arithmetic relies on a sane FRI schedule
   return ProofLayout(*p).total;
 }
 extern "C" int lcp2_last_challenges(const lcp2_circuit *c, uint64_t out[97]) {
@@ -498,8 +506,17 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
     d_wires = c->wires_vals.u();
   }
   c->stage = lcp2_circuit::ST_NONE;
-  if (d_coeffs) LCP2_TRY(commit_coeffs_dev(ctx, d_coeffs, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, true));
-  else LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires));
+  // The caller's buffer may hold non-canonical values (any u64): the transforms and K5 canonicalise what they load, the witness
+  // check of the quotient stage does not.  The bit-reversal of the iNTT, which reads every value anyway, reports whether one is
+  // >= p (no extra traffic); stage_perm_zs then takes a canonical copy before anything reads the values again.
+  unsigned long long *d_flag = (unsigned long long *)(c->small.u() + SMALL_NONCANON);
+  LCP2_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, s));
+  if (d_coeffs) {
+    LCP2_TRY(commit_coeffs_dev(ctx, d_coeffs, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, true));
+    launch_canon_copy(s, d_wires, nullptr, (u64)W * n, d_flag);  // the values did not pass through an iNTT here: scan them
+  } else {
+    LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, d_flag));
+  }
   LCP2_TRY(download_cap(c, c->wires, cap_out));
   c->d_wires_cur = d_wires;
   c->stage = lcp2_circuit::ST_WIRES;
@@ -517,7 +534,14 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
   for (u32 k = 0; k < CH; k++) { bc[k] = gl_canon(betas[k]); gc[k] = gl_canon(gammas[k]); }
   LCP2_HIP(ctx, hipMemcpyAsync(d_betas, bc, CH * 8, hipMemcpyHostToDevice, s));
   LCP2_HIP(ctx, hipMemcpyAsync(d_gammas, gc, CH * 8, hipMemcpyHostToDevice, s));
+  u64 noncanonical = 0;
+  LCP2_HIP(ctx, hipMemcpyAsync(&noncanonical, d_small + SMALL_NONCANON, 8, hipMemcpyDeviceToHost, s));
   LCP2_HIP(ctx, hipStreamSynchronize(s));
+  if (noncanonical) {  // rare: a witness with values in [p, 2^64): continue from a canonical copy (stage_wires)
+    LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
+    launch_canon_copy(s, d_wires, c->wires_vals.u(), (u64)W * n, nullptr);  // (a host witness is already the library's copy: in place)
+    d_wires = c->d_wires_cur = c->wires_vals.u();
+  }
   // ---- K5: Z and partial products on H
   {
     PermArgs a{};

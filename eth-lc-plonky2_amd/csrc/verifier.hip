@@ -267,8 +267,11 @@ bool walk_proof(const lcp2_params &p, Word &&word, Count &&count) {
   }
   return run(L.final_poly, 2 * L.final_len) && run(L.pow_witness, 1);
 }
+// the full shape check of build(): ProofLayout subtracts the FRI arities from the LDE height in unsigned arithmetic, so a schedule that
+// does not fit (a single arity of 31, a sum above degree_bits) must be refused before any layout is computed
 bool params_ok(const lcp2_params *p) {
-  return p && p->degree_bits >= 1 && p->degree_bits + p->rate_bits <= 30 && p->cap_height <= p->degree_bits + p->rate_bits &&
+  bool unsupported;
+  return p && !params_problem(*p, &unsupported) && p->degree_bits >= 1 && p->degree_bits + p->rate_bits <= 30 && p->cap_height <= p->degree_bits + p->rate_bits &&
          p->num_fri_layers <= LCP2_MAX_FRI_LAYERS && p->num_query_rounds <= 64 && p->quotient_degree_factor >= 1 && p->num_routed_wires >= 1 &&
          p->num_routed_wires <= p->num_wires && p->num_wires <= 65535 && p->num_constants <= 65535 && p->num_challenges >= 1 && p->num_challenges <= 4;
 }

@@ -293,7 +293,12 @@ int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const
  *   lcp2_quotient      compute_quotient_polys + from_coeffs                       -> quotient cap          (K6, K1-K4)
  *   lcp2_fri_open      OpeningSet::new + PolynomialBatch::prove_openings           -> openings + FriProof   (K7-K9, a13)
  * betas/gammas/alphas: num_challenges base-field elements each; caps: 4 << cap_height words;
- * public_inputs_hash: the 4 elements of hash_no_pad(public inputs), as compute_quotient_polys takes it. */
+ * public_inputs_hash: the 4 elements of hash_no_pad(public inputs), as compute_quotient_polys takes it.
+ * LIFETIME of a device witness: with wires_mem = LCP2_MEM_DEVICE the library keeps the caller's pointer, not a copy - the
+ * permutation argument (lcp2_perm_zs) and the witness check behind LCP2_E_UNSAT (lcp2_quotient / lcp2_quotient_values) read the
+ * values again.  The buffer must stay valid and unchanged until lcp2_quotient[_values] has returned (lcp2_prove: until it
+ * returns).  A host witness is copied by lcp2_commit_wires and may be released as soon as that call returns.  The values may
+ * be non-canonical (any u64) in either case. */
 int lcp2_commit_wires(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, uint64_t *cap);
 int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap);
 int lcp2_quotient(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4], uint64_t *cap);

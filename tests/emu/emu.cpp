@@ -71,9 +71,12 @@ struct EmuBackend {
         for (u32 t = 0; t < 256; t++) b.store(lds.data(), t, 256, w, c);
       }
   }
-  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols) {
+  void launch_bitrev_small(const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols, unsigned long long *noncanonical) {
     for (u32 c = 0; c < cols; c++)
-      for (u32 i = 0; i < (1u << lg); i++) out[c * os + bitrev32(i, lg)] = gl_canon(in[c * is + i]);
+      for (u32 i = 0; i < (1u << lg); i++) {
+        if (noncanonical && in[c * is + i] >= GL_P) *noncanonical = 1;
+        out[c * os + bitrev32(i, lg)] = gl_canon(in[c * is + i]);
+      }
   }
 };
 

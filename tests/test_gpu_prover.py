@@ -85,6 +85,48 @@ def test_workspace_reuse_and_device_resident_witness(gpu_ctx, oracle):
     oc.close()
 
 
+@pytest.mark.parametrize("device_witness", [False, True])
+def test_non_canonical_witness_proves_like_its_canonical_form(gpu_ctx, oracle, device_witness):
+    """lcp2.h accepts any u64 as a field element.  A witness with p added to a few hundred cells (values in [p, 2^64)) - gate
+    outputs, routed cells, PoseidonGate state - proves to the SAME proof as its canonical form, from host and from device memory
+    (there the library keeps the caller's pointer: the iNTT's bit-reversal reports the non-canonical values and the witness check
+    and K5 continue from a canonical copy); with a real violation added it is still LCP2_E_UNSAT, not a false accept."""
+    import torch
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(8, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=21, small_values=True)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    want = data.prove(wires, pis)
+    rng = np.random.default_rng(5)
+    P = np.uint64(m.GOLDILOCKS_P)
+    lifted = wires.copy()
+    room = lifted < np.uint64(2 ** 32 - 1)          # x + p < 2^64  <=>  x < 2^32 - 1
+    idx = np.argwhere(room)
+    for r, c in idx[rng.choice(len(idx), size=600, replace=False)]:
+        lifted[r, c] += P
+    assert (lifted >= P).sum() == 600 and ((lifted % P) == wires).all()
+
+    def prove(w):
+        if not device_witness:
+            return data.prove(w, pis)
+        t = torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        out = data.prove(t.data_ptr(), pis, mem=m.MEM_DEVICE)
+        assert (t.cpu().numpy().view(np.uint64) == w).all()  # the caller's buffer is not written
+        return out
+
+    assert (prove(lifted) == want).all()
+    assert (prove(wires) == want).all()
+    arith = int(np.nonzero(circ.constants_sigmas[0] == circ.gateset.index("ArithmeticGate"))[0][2])
+    bad = lifted.copy()
+    bad[7, arith] = (bad[7, arith] % P) ^ np.uint64(1)
+    with pytest.raises(m.Lcp2Error) as e:
+        prove(bad)
+    assert e.value.status == -5
+    assert (prove(lifted) == want).all()  # and the handle is fine afterwards
+    data.close()
+
+
 def test_unsatisfied_witness_is_an_error(gpu_ctx, oracle):
     """prove() of an unsatisfiable witness is an Err in plonky2 (the reference's #[should_panic] tests): lcp2_prove returns
     LCP2_E_UNSAT for a violated gate constraint (checked over the rows of H on the device) and for a broken copy constraint

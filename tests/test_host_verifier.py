@@ -159,6 +159,29 @@ def test_verifier_create_checks_the_parameters(oracle, kw):
         circ.params = good
 
 
+@pytest.mark.parametrize("arities", [[31], [4, 4, 4], [5, 5], [0], [4, 4]])
+def test_layout_entry_points_refuse_a_fri_schedule_that_does_not_fit(arities):
+    """ProofLayout subtracts the arities from the LDE height in unsigned arithmetic: a single arity of 31, or a schedule whose sum
+    exceeds degree_bits (7 here), would underflow into an undefined shift and a walk over ~2^32 sibling words.  Every entry point
+    that computes a layout runs the full shape check of build() first (no abort, no hang across the ABI)."""
+    import ctypes
+    import eth_lc_plonky2_amd as m
+    lib = m.load_library()
+    p = _variant(m, 7, fri_arity_bits=arities)
+    assert lib.lcp2_proof_words(ctypes.byref(p)) == 0
+    with pytest.raises(m.Lcp2Error):
+        m.proof_layout(p)
+    lib.lcp2_proof_bytes.restype = ctypes.c_size_t
+    assert lib.lcp2_proof_bytes(ctypes.byref(p), ctypes.c_size_t(4), ctypes.c_uint32(1)) == 0
+    with pytest.raises(m.Lcp2Error):
+        m.proof_to_bytes(p, np.zeros(16, dtype=np.uint64), np.zeros(4, dtype=np.uint64))
+    with pytest.raises(m.Lcp2Error):
+        m.proof_from_bytes(p, b"\0" * 64, 4)
+    # a schedule that does fit still works
+    ok = _variant(m, 7, fri_arity_bits=[2, 1])
+    assert lib.lcp2_proof_words(ctypes.byref(ok)) == m.proof_layout(ok).total > 0
+
+
 def test_verify_refuses_a_proof_of_the_wrong_length(oracle):
     import eth_lc_plonky2_amd as m
     params = m.standard_params(5, 4)
