@@ -75,7 +75,7 @@ def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
         return None
 
 
-def real_lc_step(extra_committees=0, recursive=False):
+def real_lc_step(extra_committees=0, recursive=False, sync_committee_only=False):
     """Not the headline number: the reference's own update pair 633 -> 634 through examples/lc_prover (the C++ host layer's
     light-client circuit in its own SHA-256 layout), if the binary has been built.  The proof time includes the device-side witness
     generation (K10).  extra_committees = 6 adds six more SyncCommitteeSSZ gadgets: 7 207 two_to_one_sha256, 2.24 M gates, 2^22 rows -
@@ -96,7 +96,8 @@ def real_lc_step(extra_committees=0, recursive=False):
                 paths.append(os.path.join(d, "u%s.json" % tag))
                 json.dump(lc[tag], open(paths[-1], "w"))
             env = dict(os.environ, LCP2_PROF="1")
-            r = subprocess.run([exe] + paths + ["--repeat", "3", "--extra-committees", str(extra_committees)] + (["--bls-proof-stand-in"] if recursive else []),
+            r = subprocess.run([exe] + paths + ["--repeat", "3", "--extra-committees", str(extra_committees)] + (["--bls-proof-stand-in"] if recursive else [])
+                               + (["--sync-committee-only"] if sync_committee_only else []),
                                capture_output=True, text=True, timeout=600, env=env)
         ms = [float(x) for x in re.findall(r"proved in ([0-9.]+) ms", r.stdout)]
         bits = re.search(r"degree_bits (\d+)", r.stdout)
@@ -105,6 +106,9 @@ def real_lc_step(extra_committees=0, recursive=False):
         if r.returncode != 0 or len(ms) < 3 or not bits:
             return None
         what = "light-client step for updates 633 -> 634 (examples/lc_prover)"
+        if sync_committee_only:
+            what = ("configs[1]: the SyncCommitteeSSZ gadget alone (512 pubkeys + aggregate key of update 634's next_sync_committee -> SSZ root, 1 025 "
+                    "two_to_one_sha256; the reference's test_ssz_sync_committee), root checked against the native SSZ root")
         inner = re.search(r"inner proof .*: 2\^(\d+) rows, (\d+) public inputs, build ([0-9.]+) ms, inner prove ([0-9.]+) ms", r.stdout)
         if recursive and inner:
             what += (" with the recursive verification of a 2^%s-row inner proof that has the BLS proof's %s public inputs (stand-in statement circuit; "
@@ -411,6 +415,9 @@ def main():
             step_633 = real_lc_step()
             if step_633:
                 out["config"]["real_lc_step"] = step_633
+            ssz = real_lc_step(sync_committee_only=True)
+            if ssz:
+                out["config"]["sync_committee_ssz"] = ssz
             rec = real_lc_step(recursive=True)
             if rec:
                 out["config"]["real_lc_step_recursive"] = rec

@@ -109,6 +109,7 @@ def load_library():
         "lcp2_sha256_tree": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint32, c.c_size_t, c.c_void_p, c.c_void_p, c.c_int]),
         "lcp2_sha256_witness": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint32, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64, c.c_void_p]),
         "lcp2_scatter_cells": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64]),
+        "lcp2_poseidon_gate_rows": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64]),
         "lcp2_buffer_alloc": (c.c_int, [c.c_void_p, c.c_size_t, c.POINTER(c.c_void_p)]),
         "lcp2_buffer_free": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_buffer_zero": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t]),

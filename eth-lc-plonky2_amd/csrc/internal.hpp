@@ -106,6 +106,8 @@ struct CellDev;
 void launch_sha_jobs_level(hipStream_t s, const ShaJobDev *jobs, u32 first, u32 count, const uint32_t *words_in, uint32_t *rec);
 void launch_sha_fill_rows(hipStream_t s, const ShaJobDev *jobs, u32 njobs, const uint32_t *rec, u64 *wires, u64 n);
 void launch_scatter_cells(hipStream_t s, const CellDev *cells, u64 ncells, u64 *wires, u64 n);
+struct PoseidonRowDev;
+void launch_poseidon_gate_rows(hipStream_t s, const PoseidonRowDev *rows, u64 nrows, u64 *wires, u64 n, const u64 *rc);
 
 // ---- device-side NTT backend over the launch wrappers ----
 struct DeviceNttBackend {

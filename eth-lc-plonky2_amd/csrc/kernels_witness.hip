@@ -11,6 +11,7 @@
 // plus k_scatter_cells for the handful of non-SHA cells (constants, arithmetic glue, public inputs).
 #include "internal.hpp"
 #include "sha_layout.hpp"
+#include "poseidon.hpp"
 
 namespace lcp2 {
 
@@ -169,6 +170,56 @@ __global__ void k_scatter_cells(const CellDev *__restrict__ cells, u64 ncells, u
   if (i >= ncells) return;
   const CellDev c = cells[i];
   wires[(u64)c.col * n + c.row] = c.value;
+}
+
+// One lane per PoseidonGate row: the permutation in its plain round form (constants, S-box, MDS), recording what enters every
+// S-box that has a wire - plonky2 gates/poseidon.rs PoseidonGenerator::run_once; wire layout as in kernels_prover.hip
+// q_poseidon_native.  A few thousand rows per light-client proof (the recursive verifier's Merkle paths, its Challenger and the
+// sponge over the inner proof's public inputs): canonical arithmetic throughout, speed is irrelevant here.
+__global__ void k_poseidon_gate_rows(const PoseidonRowDev *__restrict__ rows, u64 nrows, u64 *__restrict__ wires, u64 n, const u64 *__restrict__ rc) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const PoseidonRowDev job = rows[i];
+  u64 *W = wires + job.row;
+  auto put = [&](u32 col, u64 v) { W[(u64)col * n] = v; };
+  u64 s[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) { s[j] = gl_canon(job.in[j]); put(j, s[j]); }
+  const bool swap = job.swap != 0;
+  put(24, swap ? 1 : 0);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u64 delta = swap ? gl_sub(s[j + 4], s[j]) : 0;
+    put(25 + j, delta);
+    const u64 l = gl_add(s[j], delta), r = gl_sub(s[j + 4], delta);
+    s[j] = l; s[j + 4] = r;
+  }
+#pragma unroll 1
+  for (int round = 0; round < POS_ROUNDS; round++) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = gl_add(s[j], rc[12 * round + j]);
+    const bool full = round < POS_FULL_HALF || round >= POS_FULL_HALF + POS_PARTIAL;
+    if (full) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        if (round >= 1 && round < POS_FULL_HALF) put(29 + 12 * (round - 1) + j, s[j]);
+        if (round >= POS_FULL_HALF + POS_PARTIAL) put(87 + 12 * (round - POS_FULL_HALF - POS_PARTIAL) + j, s[j]);
+        s[j] = gl_canon(pos_sbox(s[j]));
+      }
+    } else {
+      put(65 + (round - POS_FULL_HALF), s[0]);
+      s[0] = gl_canon(pos_sbox(s[0]));
+    }
+    pos_mds(s);
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = gl_canon(s[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 12; j++) put(12 + j, s[j]);
+}
+void launch_poseidon_gate_rows(hipStream_t s, const PoseidonRowDev *rows, u64 nrows, u64 *wires, u64 n, const u64 *rc) {
+  if (!nrows) return;
+  hipLaunchKernelGGL(k_poseidon_gate_rows, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, s, rows, nrows, wires, n, rc);
 }
 
 void launch_sha_jobs_level(hipStream_t s, const ShaJobDev *jobs, u32 first, u32 count, const uint32_t *words_in, uint32_t *rec) {

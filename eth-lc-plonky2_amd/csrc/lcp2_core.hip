@@ -547,6 +547,22 @@ extern "C" int lcp2_scatter_cells(lcp2_ctx *ctx, const lcp2_cell *cells, size_t 
   return LCP2_OK;
 }
 
+extern "C" int lcp2_poseidon_gate_rows(lcp2_ctx *ctx, const lcp2_poseidon_row *rows, size_t nrows, uint64_t *wires, uint64_t n) {
+  static_assert(sizeof(lcp2_poseidon_row) == sizeof(PoseidonRowDev), "row job layouts must agree");
+  if (!ctx || !wires || (nrows && !rows)) return LCP2_E_INVALID;
+  if (!nrows) return LCP2_OK;
+  for (size_t i = 0; i < nrows; i++)
+    if (rows[i].row >= n || rows[i].swap > 1) return ctx->fail(LCP2_E_INVALID, "poseidon rows: row out of range or swap flag not boolean");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  LCP2_HIP(ctx, d.alloc(nrows * sizeof(lcp2_poseidon_row)));
+  LCP2_HIP(ctx, hipMemcpyAsync(d.p, rows, nrows * sizeof(lcp2_poseidon_row), hipMemcpyHostToDevice, ctx->stream));
+  launch_poseidon_gate_rows(ctx->stream, (const PoseidonRowDev *)d.p, nrows, (u64 *)wires, n, ctx->d_rc);
+  LCP2_HIP(ctx, hipGetLastError());
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the job list is freed on return
+  return LCP2_OK;
+}
+
 extern "C" int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev) {
   if (!ctx || !dev) return LCP2_E_INVALID;
   LCP2_HIP(ctx, hipSetDevice(ctx->device));

@@ -24,4 +24,8 @@ struct CellDev {            // = lcp2_cell
   uint32_t row, col;
   uint64_t value;
 };
+struct PoseidonRowDev {     // = lcp2_poseidon_row: one PoseidonGate row to generate (kernels_witness.hip k_poseidon_gate_rows)
+  uint32_t row, swap;
+  unsigned long long in[12];
+};
 }  // namespace lcp2

@@ -7,6 +7,11 @@
 // forward pass replaces plonky2's worklist); a value set twice with different results is the UnsatisfiedError
 // that makes the reference's #[should_panic] tests panic.
 #include <cstdio>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <map>
+#include <thread>
 #include "host_internal.hpp"
 
 namespace lc {
@@ -322,6 +327,9 @@ std::unique_ptr<CircuitData> CircuitBuilder::build() {
   F w = f_root_of_unity(degree_bits);
   sub[0] = 1;
   for (uint64_t i = 1; i < n; i++) sub[i] = f_mul(sub[i - 1], w);
+  // no connect() after this point: flatten the union-find (every variable points at its root), so that the find() of every
+  // generator input and wire cell during witness generation is one step instead of a walk
+  for (uint32_t v = 0; v < d->parent.size(); v++) d->parent[v] = d->find(v);
   // identity permutation, then one cycle per variable class
   uint64_t *sig = D.constants_sigmas.data() + (size_t)NC * n;
   for (uint32_t j = 0; j < NR; j++)
@@ -362,15 +370,20 @@ struct Values {
   std::vector<F> val;
   std::vector<uint8_t> has;
   explicit Values(const CircuitData::Impl *dd) : d(dd), val(dd->parent.size(), 0), has(dd->parent.size(), 0) {}
+  // The generators of one phase may run on several threads (run_host_phase): a value is published by the release store of its
+  // flag and read after an acquire load of it.  Two generators never produce the same class with different values in a
+  // satisfiable witness; when they do, one of them sees the other's value and throws, as on one thread.
+  bool known(uint32_t r) const { return __atomic_load_n(&has[r], __ATOMIC_ACQUIRE) != 0; }
   void set(uint32_t var, F v, const char *what) {
     uint32_t r = d->find(var);
-    if (has[r] && val[r] != v)
+    if (known(r) && val[r] != v)
       throw UnsatisfiedError(std::string("witness conflict on a connected target (") + what + "): " + std::to_string(val[r]) + " vs " + std::to_string(v));
-    val[r] = v; has[r] = 1;
+    val[r] = v;
+    __atomic_store_n(&has[r], (uint8_t)1, __ATOMIC_RELEASE);
   }
   F get(uint32_t var, const char *what) const {
     uint32_t r = d->find(var);
-    if (!has[r]) throw UnsatisfiedError(std::string("target has no value: ") + what);
+    if (!known(r)) throw UnsatisfiedError(std::string("target has no value: ") + what);
     return val[r];
   }
 };
@@ -466,6 +479,21 @@ static void eval_poseidon(const Op &op, Values &V, std::vector<lcp2_cell> &raw) 
   for (uint32_t c = POS_WIRE_DELTA; c < POS_GATE_WIRES; c++) raw.push_back(lcp2_cell{op.first_row, c, row[c]});
 }
 
+// The same generator when the rows are filled on the device (generate_witness_gpu): only the 12 outputs are computed here, the
+// row is queued as (row, inputs, swap) for lcp2_poseidon_gate_rows
+static void eval_poseidon_outputs(const Op &op, Values &V, std::vector<lcp2_poseidon_row> &rows) {
+  lcp2_poseidon_row job{};
+  F out[12];
+  for (int i = 0; i < 12; i++) job.in[i] = V.get(op.in[i], "poseidon input");
+  const F swap = V.get(op.x, "poseidon swap flag");
+  if (swap > 1) throw UnsatisfiedError("poseidon swap flag is not boolean");
+  job.row = op.first_row;
+  job.swap = (uint32_t)swap;
+  poseidon_gate_outputs(job.in, swap == 1, out);
+  for (int i = 0; i < 12; i++) V.set(op.internal[i], out[i], "poseidon output");
+  rows.push_back(job);
+}
+
 // split_le generator: the low c0 bits of x; a value that does not fit cannot satisfy the recomposition constraint
 static void eval_bits(const Op &op, Values &V) {
   const F x = V.get(op.x, "split_le input");
@@ -478,7 +506,7 @@ static inline F f_inv(F x) { return f_pow(x, GOLDILOCKS_P - 2); }
 
 // every generator that runs on the host (everything but SHA): is it ready, and run it
 static bool host_op_ready(const Op &op, const Values &V) {
-  auto has = [&](uint32_t v) { return V.has[V.d->find(v)] != 0; };
+  auto has = [&](uint32_t v) { return V.known(V.d->find(v)); };
   switch (op.kind) {
     case Op::ARITH: return has(op.x) && has(op.y) && has(op.z);
     case Op::BITS: case Op::INV: case Op::SPLIT32: return has(op.x);
@@ -574,6 +602,128 @@ void CircuitData::attach_gpu(lcp2_ctx *ctx) {
     throw std::runtime_error(std::string("witness buffer: ") + lcp2_last_error(ctx));
 }
 
+// ---- One host phase of generate_witness_gpu: every host generator that is, or becomes, ready.
+// The recursive verifier puts thousands of PoseidonGate rows into the light-client circuit - 3 152 of them the sponge over the
+// inner proof's public inputs, sequential by construction, the rest Merkle paths and the Challenger, short chains that are
+// independent of each other - and one permutation costs the host 4-6 us.  The generators are therefore spread over LANES (threads):
+// PoseidonGate generators that feed one another directly form a chain and a chain stays on one lane (largest chains first, each
+// to the least loaded lane), everything else (arithmetic, bit splits: cheap) shares the last lane.  Every lane sweeps its own list
+// in creation order, runs what is ready and keeps what is not, as the single-threaded worklist does; a phase ends when every lane
+// has either emptied its list or swept it without anything having happened anywhere in the meantime.
+static HostLanes plan_host_lanes(const CircuitData::Impl *d, unsigned max_lanes) {
+  HostLanes L;
+  const size_t nops = d->ops.size();
+  L.lane_of_op.assign(nops, 0);
+  std::vector<uint32_t> pos;  // indices of the PoseidonGate generators
+  for (size_t i = 0; i < nops; i++) if (d->ops[i].kind == Op::POSEIDON) pos.push_back((uint32_t)i);
+  if (max_lanes < 2 || pos.size() < 512) return L;  // not worth a thread
+  // chains: union-find over "an input of q is an output of p"
+  std::map<uint32_t, uint32_t> producer;  // variable class -> position in pos
+  for (uint32_t k = 0; k < pos.size(); k++)
+    for (uint32_t v : d->ops[pos[k]].internal) producer[d->find(v)] = k;
+  std::vector<uint32_t> parent(pos.size());
+  for (uint32_t k = 0; k < pos.size(); k++) parent[k] = k;
+  std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { while (parent[x] != x) x = parent[x] = parent[parent[x]]; return x; };
+  for (uint32_t k = 0; k < pos.size(); k++)
+    for (int i = 0; i < 12; i++) {
+      auto it = producer.find(d->find(d->ops[pos[k]].in[i]));
+      if (it != producer.end()) parent[find(k)] = find(it->second);
+    }
+  std::map<uint32_t, std::vector<uint32_t>> chains;
+  for (uint32_t k = 0; k < pos.size(); k++) chains[find(k)].push_back(k);
+  std::vector<const std::vector<uint32_t> *> by_size;
+  for (auto &c : chains) by_size.push_back(&c.second);
+  std::sort(by_size.begin(), by_size.end(), [](const std::vector<uint32_t> *a, const std::vector<uint32_t> *b) { return a->size() != b->size() ? a->size() > b->size() : (*a)[0] < (*b)[0]; });
+  L.lanes = max_lanes;
+  std::vector<size_t> load(L.lanes, 0);
+  load[L.lanes - 1] = (nops - pos.size()) / 40;  // the cheap generators: about 1/40 of a permutation each
+  for (const auto *c : by_size) {
+    const unsigned lane = (unsigned)(std::min_element(load.begin(), load.end()) - load.begin());
+    for (uint32_t k : *c) L.lane_of_op[pos[k]] = (uint8_t)lane;
+    load[lane] += c->size();
+  }
+  for (size_t i = 0; i < nops; i++) if (d->ops[i].kind != Op::POSEIDON) L.lane_of_op[i] = (uint8_t)(L.lanes - 1);
+  return L;
+}
+
+struct HostPhaseStats { size_t sweeps = 0, visits = 0; };
+// host_ops: the generators still waiting (in creation order); on return those that are waiting for something this phase cannot
+// produce (a SHA-256 digest of the next device batch - or nothing at all: the caller tells these apart at the end)
+static void run_host_phase(const CircuitData::Impl *d, const HostLanes &L, std::vector<const Op *> &host_ops, Values &V, std::vector<lcp2_cell> &cells,
+                           std::vector<lcp2_poseidon_row> &pos_rows, HostPhaseStats &st) {
+  auto sweep = [&](std::vector<const Op *> &mine, std::vector<lcp2_cell> &my_cells, std::vector<lcp2_poseidon_row> &my_rows, std::atomic<uint64_t> *epoch) {
+    bool progress = false;
+    std::vector<const Op *> waiting;
+    for (const Op *op : mine) {
+      if (!host_op_ready(*op, V)) { waiting.push_back(op); continue; }
+      if (op->kind == Op::POSEIDON) eval_poseidon_outputs(*op, V, my_rows);
+      else host_op_eval(*op, V, my_cells);
+      if (epoch) epoch->fetch_add(1, std::memory_order_release);
+      progress = true;
+    }
+    st.visits += mine.size();  // (racy across lanes: a statistic)
+    st.sweeps++;
+    mine.swap(waiting);
+    return progress;
+  };
+  size_t npos = 0;
+  for (const Op *op : host_ops) npos += op->kind == Op::POSEIDON;
+  if (L.lanes < 2 || npos < 512) {  // the single-threaded worklist
+    while (!host_ops.empty() && sweep(host_ops, cells, pos_rows, nullptr)) {}
+    return;
+  }
+  const unsigned K = L.lanes;
+  std::vector<std::vector<const Op *>> mine(K);
+  std::vector<std::vector<lcp2_cell>> lane_cells(K);
+  std::vector<std::vector<lcp2_poseidon_row>> lane_rows(K);
+  for (const Op *op : host_ops) mine[L.lane_of_op[(size_t)(op - d->ops.data())]].push_back(op);
+  std::atomic<uint64_t> epoch{0};
+  std::atomic<int> active{(int)K}, idle{0};
+  std::atomic<bool> stop{false};
+  std::vector<std::exception_ptr> failure(K);
+  auto lane_main = [&](unsigned k) {
+    try {
+      unsigned backoff = 0;
+      while (!stop.load(std::memory_order_acquire) && !mine[k].empty()) {
+        const uint64_t e0 = epoch.load(std::memory_order_acquire);
+        if (sweep(mine[k], lane_cells[k], lane_rows[k], &epoch)) { backoff = 0; continue; }
+        if (epoch.load(std::memory_order_acquire) != e0) {
+          // other lanes are producing values, none of them for this lane yet (the verifier's Merkle paths wait for query indices that
+          // wait for the sponge): look again after a pause that doubles up to 256 us, instead of re-reading the whole list (and the
+          // cache lines the busy lanes write) for every value somebody else produces
+          const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(1u << backoff);
+          while (!stop.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+          if (backoff < 8) backoff++;
+          continue;
+        }
+        // nothing happened anywhere while this lane looked at all it has: wait for news, or find that every lane is in this state
+        idle.fetch_add(1, std::memory_order_acq_rel);
+        while (!stop.load(std::memory_order_acquire) && epoch.load(std::memory_order_acquire) == e0) {
+          if (idle.load(std::memory_order_acquire) >= active.load(std::memory_order_acquire)) stop.store(true, std::memory_order_release);
+          else std::this_thread::yield();
+        }
+        idle.fetch_sub(1, std::memory_order_acq_rel);
+      }
+    } catch (...) {
+      failure[k] = std::current_exception();
+      stop.store(true, std::memory_order_release);
+    }
+    active.fetch_sub(1, std::memory_order_acq_rel);
+  };
+  std::vector<std::thread> threads;
+  for (unsigned k = 1; k < K; k++) threads.emplace_back(lane_main, k);
+  lane_main(0);
+  for (auto &t : threads) t.join();
+  for (unsigned k = 0; k < K; k++) if (failure[k]) std::rethrow_exception(failure[k]);
+  host_ops.clear();
+  for (unsigned k = 0; k < K; k++) {
+    host_ops.insert(host_ops.end(), mine[k].begin(), mine[k].end());
+    cells.insert(cells.end(), lane_cells[k].begin(), lane_cells[k].end());
+    pos_rows.insert(pos_rows.end(), lane_rows[k].begin(), lane_rows[k].end());
+  }
+  std::sort(host_ops.begin(), host_ops.end());  // creation order again
+}
+
 // generate_partial_witness with the SHA-256 generators on the device.  Host and device alternate until every
 // generator has run: the host evaluates constants / arithmetic from its worklist, then every two_to_one_sha256
 // whose message is known (directly, or as the digest of another hash of the same batch) goes to the GPU as one
@@ -586,19 +736,27 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   for (auto &e : pw.entries()) V.set(e.first, e.second, "PartialWitness");
   std::vector<const Op *> host_ops, sha_ops;
   for (const Op &op : d->ops) (op.kind == Op::SHA ? sha_ops : host_ops).push_back(&op);
-  std::vector<lcp2_cell> cells;  // everything the host writes: unbound cells of PoseidonGate rows, then the bound cells
+  std::vector<lcp2_cell> cells;               // what the host writes cell by cell: the bound cells of the non-SHA, non-Poseidon rows
+  std::vector<lcp2_poseidon_row> pos_rows;    // PoseidonGate rows: generated on the device from (row, inputs, swap)
+  const bool prof = getenv("LCP2_PROF") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  double t_host = 0, t_sha = 0;
+  if (d->host_lanes.lane_of_op.size() != d->ops.size()) {
+    // One lane unless LCP2_HOST_LANES asks for more.  Measured on the light-client circuit with the recursive verifier (EPYC 9575F,
+    // profiles/r03_host_witness.md): one lane 9.8 ms, eight lanes 8.4-9.5 ms with outliers of 17 ms - everything the verifier does
+    // waits for the sponge over the inner public inputs (it is observed into the transcript first), so the lanes have only the 40 %
+    // after it to share, and thread start-up and hand-offs eat most of that.
+    unsigned want = 1;
+    if (const char *e = getenv("LCP2_HOST_LANES")) want = (unsigned)atoi(e);
+    d->host_lanes = plan_host_lanes(d, std::max(1u, std::min(want, 8u)));
+  }
+  HostPhaseStats st;
+  const auto t_begin = now();
   while (true) {
-    bool progress = true;
-    while (progress && !host_ops.empty()) {  // host worklist
-      progress = false;
-      std::vector<const Op *> waiting;
-      for (const Op *op : host_ops) {
-        if (!host_op_ready(*op, V)) { waiting.push_back(op); continue; }
-        host_op_eval(*op, V, cells);
-        progress = true;
-      }
-      host_ops.swap(waiting);
-    }
+    const auto t0 = now();
+    run_host_phase(d, d->host_lanes, host_ops, V, cells, pos_rows, st);
+    t_host += ms(t0, now());
     if (sha_ops.empty()) break;
     // plan one device batch
     std::map<uint32_t, uint32_t> produced;  // variable class -> slot * 8 + word
@@ -652,14 +810,25 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     sha_ops.swap(later);
   }
   if (!host_ops.empty()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
-  // the cells of the non-SHA rows
+  const auto t_rows = now();
+  // the PoseidonGate rows: every wire of a row from its inputs (the values bound to its input / output / swap cells are the ones
+  // the jobs were made from: a conflicting connection has already thrown in V.set)
+  int rc = lcp2_poseidon_gate_rows(d->ctx, pos_rows.data(), pos_rows.size(), (uint64_t *)d->d_wires, n);
+  if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_poseidon_gate_rows: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
+  // the cells of the remaining rows
   for (const CellBinding &c : d->cells) {
     uint32_t g = d->gate_of_row[c.row];
-    if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED) continue;
+    if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED || g == G_POSEIDON) continue;
     cells.push_back(lcp2_cell{c.row, c.col, V.get(c.var, "wire cell")});
   }
-  int rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);
+  const auto t_scatter = now();
+  rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_scatter_cells: ") + lcp2_status_str(rc));
+  if (prof)
+    printf("  witness generation %.2f ms: host generators %.2f ms on %u lane(s) (%zu sweeps, %zu visits of %zu ops, %zu PoseidonGate rows), SHA-256 batches %.2f ms, "
+           "PoseidonGate rows on the device + cell list %.2f ms, scatter of %zu cells %.2f ms\n",
+           ms(t_begin, now()), t_host, d->host_lanes.lanes, st.sweeps, st.visits, d->ops.size(), pos_rows.size(), ms(t_begin, t_rows) - t_host, ms(t_rows, t_scatter), cells.size(), ms(t_scatter, now()));
+  (void)t_sha;
   public_inputs.clear();
   for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
 }

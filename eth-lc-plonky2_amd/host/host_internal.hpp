@@ -27,6 +27,8 @@ inline uint32_t pos_wire_full_sbox_0(uint32_t round, uint32_t i) { return POS_WI
 inline uint32_t pos_wire_full_sbox_1(uint32_t round, uint32_t i) { return POS_WIRE_FULL_1 + 12 * round + i; }
 const uint64_t *poseidon_round_constants();                    // 360 values
 void poseidon_gate_row(const F in[12], bool swap, F row[135]); // PoseidonGenerator::run_once: every wire of one row
+void poseidon_gate_outputs(const F in[12], bool swap, F out[12]); // the 12 output wires alone (the row itself is generated on the device)
+void poseidon_gate_outputs_impl(const F in[12], bool swap, F out[12], bool portable);  // the same, optionally without AVX2 (tests)
 extern const uint32_t GATE_DEGREE[G_COUNT];
 
 // ---- Goldilocks on the host (circuit construction / witness generation only)
@@ -67,6 +69,11 @@ struct Op {
 };
 
 struct CellBinding { uint32_t row, col, var; };
+// which thread ("lane") runs which host generator in generate_witness_gpu (builder.cpp plan_host_lanes)
+struct HostLanes {
+  std::vector<uint8_t> lane_of_op;  // index into Impl::ops
+  unsigned lanes = 1;
+};
 
 struct CircuitData::Impl {
   CircuitConfig config;
@@ -81,6 +88,7 @@ struct CircuitData::Impl {
   void *d_wires = nullptr;                // device witness matrix [num_wires][n], zeroed once
   lcp2_circuit *gpu = nullptr;
   lcp2_circuit *verifier = nullptr;
+  HostLanes host_lanes;                   // planned at the first prove
   uint32_t find(uint32_t v) const { while (parent[v] != v) v = parent[v]; return v; }
 };
 

@@ -6,6 +6,9 @@
 // reference's in full shape: a proof with the BLS proof's 25 216 public inputs is produced first (of the STAND-IN statement
 // circuit of host/gadgets.hpp - it proves nothing about the signature; the BLS12-381 verifier is out of scope) and the
 // light-client circuit verifies it recursively and ties its public inputs to the signing root, signature, committee and bits.
+// --sync-committee-only proves the SyncCommitteeSSZ gadget alone (BASELINE configs[1]; the reference's test_ssz_sync_committee,
+// src/sync_committee_pubkeys.rs:100-653): the 512 pubkeys and the aggregate key of <cur_update>'s next_sync_committee hashed to
+// their SSZ root (1 025 two_to_one_sha256), the root a public input checked against the native SSZ root.
 // --extra-committees C adds C more SyncCommitteeSSZ gadgets (1 025 two_to_one_sha256 = 317 750 rows each) on the update's own
 // committee: with C = 6 the circuit has 7 x 1 025 + 32 hashes and 2^22 rows, the reference's scale, made of real gadgets.
 #include <chrono>
@@ -37,8 +40,8 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 }
 
 int main(int argc, char **argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s <prev_update.json> <cur_update.json> [--witness-only] [--device N] [--repeat K] [--extra-committees C] [--bls-proof-stand-in]\n", argv[0]); return 2; }
-  bool witness_only = false, bls = false;
+  if (argc < 3) { fprintf(stderr, "usage: %s <prev_update.json> <cur_update.json> [--witness-only] [--device N] [--repeat K] [--extra-committees C] [--bls-proof-stand-in] [--sync-committee-only]\n", argv[0]); return 2; }
+  bool witness_only = false, bls = false, ssz_only = false;
   int device = 0, repeat = 1, extra = 0;
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "--witness-only")) witness_only = true;
@@ -46,6 +49,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--extra-committees") && i + 1 < argc) extra = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--bls-proof-stand-in")) bls = true;
+    else if (!strcmp(argv[i], "--sync-committee-only")) ssz_only = true;
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -58,6 +62,50 @@ int main(int argc, char **argv) {
     if (!witness_only) {
       int rc = lcp2_ctx_create(device, nullptr, &ctx);
       if (rc != LCP2_OK) { fprintf(stderr, "lcp2_ctx_create(device %d): %s\n", device, lcp2_status_str(rc)); return 3; }
+    }
+    if (ssz_only) {  // BASELINE configs[1]
+      if (witness_only) { fprintf(stderr, "--sync-committee-only needs the GPU\n"); return 2; }
+      t0 = std::chrono::steady_clock::now();
+      CircuitBuilder builder(CircuitConfig::standard_recursion_config());
+      SyncCommitteeTarget sc = add_virtual_sync_committee_target(builder);
+      Hash256Target root = ssz_sync_committee(builder, sc);
+      for (auto &limb : root) builder.register_public_input(limb.t);
+      const size_t gates = builder.num_gates();
+      auto data = builder.build();
+      printf("circuit built in %.1f ms: %zu gates, degree_bits %u\n", ms_since(t0), gates, data->degree_bits());
+      PartialWitness pw;
+      for (size_t i = 0; i < SYNC_COMMITTEE_SIZE; i++)
+        pw.set_target_arr(sc.pubkeys[i], std::vector<F>(cur.next_sync_committee.pubkeys[i].begin(), cur.next_sync_committee.pubkeys[i].end()));
+      pw.set_target_arr(sc.aggregate_pubkey, std::vector<F>(cur.next_sync_committee.aggregate_pubkey.begin(), cur.next_sync_committee.aggregate_pubkey.end()));
+      const H256 want = cur.next_sync_committee.tree_hash_root();
+      data->attach_gpu(ctx);
+      const bool prof = getenv("LCP2_PROF") != nullptr;
+      for (int k = 0; k < repeat; k++) {
+        if (prof && k == repeat - 1) { lcp2_prof_enable(ctx, 1); lcp2_prof_reset(ctx); }
+        t0 = std::chrono::steady_clock::now();
+        ProofWithPublicInputs proof = data->prove(pw);
+        const double prove_ms = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        data->verify(proof);
+        for (int w = 0; w < 8; w++) {  // the public inputs are the root's eight big-endian words
+          const uint32_t word = (uint32_t)want[4 * w] << 24 | (uint32_t)want[4 * w + 1] << 16 | (uint32_t)want[4 * w + 2] << 8 | want[4 * w + 3];
+          if (proof.public_inputs.size() != 8 || proof.public_inputs[w] != word) { fprintf(stderr, "error: the proved root is not the native SSZ root\n"); return 1; }
+        }
+        printf("proof %d: proved in %.1f ms (witness generation included), verified in %.1f ms, %zu proof words, %zu public inputs, root %s\n", k, prove_ms,
+               ms_since(t0), proof.proof.size(), proof.public_inputs.size(), hex(want).c_str());
+      }
+      if (prof) {
+        static const char *names[LCP2_K_COUNT] = {"intt", "lde", "leaf_hash", "merkle", "perm_z", "quotient", "openings", "fri", "pow", "sha256_witness", "other"};
+        for (int f = 0; f < LCP2_K_COUNT; f++) {
+          double ms = 0, bytes = 0;
+          uint64_t launches = 0;
+          lcp2_prof_get(ctx, f, &ms, &launches, &bytes);
+          if (launches) printf("  %-15s %8.3f ms  (%llu scopes)\n", names[f], ms, (unsigned long long)launches);
+        }
+      }
+      data.reset();
+      lcp2_ctx_destroy(ctx);
+      return 0;
     }
     // src/main.rs:170: the BLS-signature proof first; its common data shapes the recursive verifier
     BlsStatementStandIn bls_circuit;

@@ -148,6 +148,17 @@ int lcp2_sha256_witness(lcp2_ctx *ctx, const lcp2_sha_job *jobs, size_t njobs, c
                         const uint32_t *words_in, size_t nwords, uint64_t *wires, uint64_t n, uint32_t *digests);
 /* wires[col][row] = value for a list of cells (the non-SHA rows: constants, arithmetic glue, public inputs) */
 int lcp2_scatter_cells(lcp2_ctx *ctx, const lcp2_cell *cells, size_t ncells, uint64_t *wires, uint64_t n);
+/* PoseidonGate rows generated on the device (plonky2 gates/poseidon.rs PoseidonGenerator::run_once; the reference's circuit holds
+ * thousands of them inside verify_proof, eth-lc-plonky2/src/targets.rs:468-470): one job per row = the 12 input wires and the swap
+ * flag; the kernel writes EVERY wire of the row (inputs 0..12, outputs 12..24, swap 24, delta 25..29 and the S-box inputs 29..135)
+ * into the column-major witness matrix.  The host generator then only needs the 12 outputs (a plain permutation) for the
+ * generators downstream. */
+typedef struct {
+  uint32_t row;
+  uint32_t swap;     /* 0 or 1 */
+  uint64_t in[12];   /* any u64 */
+} lcp2_poseidon_row;
+int lcp2_poseidon_gate_rows(lcp2_ctx *ctx, const lcp2_poseidon_row *rows, size_t nrows, uint64_t *wires, uint64_t n);
 
 /* device buffers for callers that keep the witness resident in HBM */
 int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev);

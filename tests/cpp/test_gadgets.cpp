@@ -20,6 +20,7 @@
 #include "../../eth-lc-plonky2_amd/host/gadgets.hpp"
 #include "../../eth-lc-plonky2_amd/host/recursion.hpp"
 #include "../../eth-lc-plonky2_amd/host/biguint.hpp"
+#include "../../eth-lc-plonky2_amd/host/host_internal.hpp"
 #include "../../oracle/oracle.h"
 #include "../../oracle/plonk.h"
 #include "golden_data.hpp"
@@ -727,6 +728,29 @@ static void test_recursive_verifier_tampered_sibling_panics() { recursive_verifi
 static void test_recursive_verifier_wrong_public_input_panics() { recursive_verifier(false, false, -1, true); }
 static void test_recursive_verifier_wrong_digest_panics() { recursive_verifier(false, false, -1, false, true); }
 
+// the outputs-only generator of a PoseidonGate row (what generate_witness_gpu runs on the host; the row itself is filled on the device)
+// against the full row generator and the oracle's permutation, swap included, non-canonical inputs included
+static void test_poseidon_gate_outputs_match_rows() {
+  uint64_t seed = 12345;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; uint64_t z = seed; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; return z ^ (z >> 32); };
+  for (int t = 0; t < 500; t++) {
+    F in[12], row[POS_GATE_WIRES], out[12];
+    for (auto &x : in) x = t < 4 ? (t == 0 ? 0 : t == 1 ? GOLDILOCKS_P - 1 : ~0ull) : rnd();
+    const bool swap = t & 1;
+    F out_portable[12];
+    poseidon_gate_row(in, swap, row);
+    poseidon_gate_outputs(in, swap, out);                         // AVX2 linear layers where the CPU has them
+    poseidon_gate_outputs_impl(in, swap, out_portable, true);     // 128-bit multiply-accumulates
+    for (int i = 0; i < 12; i++) if (out[i] != out_portable[i]) throw std::runtime_error("poseidon_gate_outputs: AVX2 and portable paths differ");
+    uint64_t s[12];
+    for (int i = 0; i < 12; i++) s[i] = in[i] % GOLDILOCKS_P;
+    if (swap) for (int i = 0; i < 4; i++) std::swap(s[i], s[i + 4]);
+    orc_poseidon_permute(s);
+    for (int i = 0; i < 12; i++)
+      if (row[POS_WIRE_OUTPUT + i] != out[i] || out[i] != s[i]) throw std::runtime_error("poseidon_gate_outputs differs from the row generator / the oracle at case " + std::to_string(t));
+  }
+}
+
 struct TestCase { const char *name; std::function<void()> fn; bool should_panic; bool gpu_only = false; };
 static const TestCase TESTS[] = {
     {"test_merkle_root_2_leaves", test_merkle_root_2_leaves, false},
@@ -766,6 +790,7 @@ static const TestCase TESTS[] = {
     {"test_update_validity_big", test_update_validity_big, false},
     {"test_update_validity_big_finalized_before_current_panics", test_update_validity_big_finalized_before_current_panics, true},
     {"test_update_validity_big_threshold_not_exceeded_panics", test_update_validity_big_threshold_not_exceeded_panics, true},
+    {"test_poseidon_gate_outputs_match_rows", test_poseidon_gate_outputs_match_rows, false},
     {"test_builder_primitives", test_builder_primitives, false},
     {"test_builder_inverse_of_zero_panics", test_builder_inverse_of_zero_panics, true},
     {"test_recursive_verifier", test_recursive_verifier, false},
