@@ -752,16 +752,43 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     d->host_lanes = plan_host_lanes(d, std::max(1u, std::min(want, 8u)));
   }
   HostPhaseStats st;
+  // the first proof of a circuit records its device batches and the host's cell list (GpuWitnessPlan); later proofs replay them
+  bool recording = !d->gpu_plan.ready;
+  GpuWitnessPlan recorded;
+  size_t n_batches = 0;
   const auto t_begin = now();
   while (true) {
     const auto t0 = now();
     run_host_phase(d, d->host_lanes, host_ops, V, cells, pos_rows, st);
     t_host += ms(t0, now());
     if (sha_ops.empty()) break;
+    const size_t batch_no = n_batches++;
+    if (d->gpu_plan.ready && batch_no < d->gpu_plan.batches.size()) {
+      // the batch as planned at the first proof: only the message words are fetched
+      const ShaBatchPlan &B = d->gpu_plan.batches[batch_no];
+      bool applies = B.ops_left < sha_ops.size();
+      std::vector<uint32_t> words(B.word_vars.size());
+      for (size_t k = 0; k < words.size() && applies; k++) {
+        if (!V.known(B.word_vars[k])) applies = false;
+        else words[k] = as_u32(V.val[B.word_vars[k]], "sha256 message word");
+      }
+      if (applies) {
+        std::vector<uint32_t> digests(B.jobs.size() * 8);
+        int rc = lcp2_sha256_witness(d->ctx, B.jobs.data(), B.jobs.size(), B.level_start.data(), (uint32_t)B.level_start.size() - 1, words.data(), words.size(),
+                                     (uint64_t *)d->d_wires, n, digests.data());
+        if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_sha256_witness: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
+        for (size_t k = 0; k < B.jobs.size(); k++)
+          for (int w = 0; w < 8; w++) V.set(B.out[k][w], digests[k * 8 + w], "sha256 digest");
+        sha_ops.resize(B.ops_left);  // only the count matters from here on: the next batch is planned too, or there is none
+        continue;
+      }
+      d->gpu_plan = GpuWitnessPlan();  // another set of witness targets than at the first proof: plan afresh, from this batch on
+      recording = false;
+    }
     // plan one device batch
     std::map<uint32_t, uint32_t> produced;  // variable class -> slot * 8 + word
     std::vector<lcp2_sha_job> jobs;
-    std::vector<uint32_t> level, words;
+    std::vector<uint32_t> level, words, word_vars;
     std::vector<const Op *> batch, later;
     for (const Op *op : sha_ops) {
       lcp2_sha_job job{};
@@ -771,14 +798,14 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       size_t words_mark = words.size();
       for (int i = 0; i < 16 && ok; i++) {
         uint32_t r = d->find(op->in[i]);
-        if (V.has[r]) { job.in_src[i] = (int32_t)words.size(); words.push_back(as_u32(V.val[r], "sha256 message word")); }
+        if (V.has[r]) { job.in_src[i] = (int32_t)words.size(); words.push_back(as_u32(V.val[r], "sha256 message word")); word_vars.push_back(r); }
         else {
           auto it = produced.find(r);
           if (it == produced.end()) ok = false;
           else { job.in_src[i] = ~(int32_t)it->second; lvl = std::max(lvl, level[it->second >> 3] + 1); }
         }
       }
-      if (!ok) { words.resize(words_mark); later.push_back(op); continue; }
+      if (!ok) { words.resize(words_mark); word_vars.resize(words_mark); later.push_back(op); continue; }
       uint32_t slot = (uint32_t)jobs.size();
       for (int w = 0; w < 8; w++) produced[d->find(op->out8[w])] = slot * 8 + w;
       jobs.push_back(job); level.push_back(lvl); batch.push_back(op);
@@ -807,6 +834,14 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_sha256_witness: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
     for (uint32_t s = 0; s < batch.size(); s++)
       for (int w = 0; w < 8; w++) V.set(batch[s]->out8[w], digests[(size_t)newslot[s] * 8 + w], "sha256 digest");
+    if (recording) {
+      ShaBatchPlan B;
+      B.jobs = sorted; B.word_vars = word_vars; B.level_start = level_start; B.ops_left = later.size();
+      B.out.resize(jobs.size());
+      for (uint32_t s = 0; s < batch.size(); s++)
+        for (int w = 0; w < 8; w++) B.out[newslot[s]][w] = d->find(batch[s]->out8[w]);
+      recorded.batches.push_back(std::move(B));
+    }
     sha_ops.swap(later);
   }
   if (!host_ops.empty()) throw UnsatisfiedError("a generator is waiting for a target that is never set");
@@ -815,11 +850,21 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   // the jobs were made from: a conflicting connection has already thrown in V.set)
   int rc = lcp2_poseidon_gate_rows(d->ctx, pos_rows.data(), pos_rows.size(), (uint64_t *)d->d_wires, n);
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_poseidon_gate_rows: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
-  // the cells of the remaining rows
-  for (const CellBinding &c : d->cells) {
-    uint32_t g = d->gate_of_row[c.row];
-    if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED || g == G_POSEIDON) continue;
-    cells.push_back(lcp2_cell{c.row, c.col, V.get(c.var, "wire cell")});
+  // the cells of the remaining rows (the list is made once: most of a light-client circuit's bindings sit on SHA-256 rows)
+  if (!d->gpu_plan.ready) {
+    GpuWitnessPlan fresh;
+    for (const CellBinding &c : d->cells) {
+      uint32_t g = d->gate_of_row[c.row];
+      if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED || g == G_POSEIDON) continue;
+      fresh.host_cells.push_back(CellBinding{c.row, c.col, d->find(c.var)});
+    }
+    if (recording) { fresh.batches = std::move(recorded.batches); fresh.ready = true; }
+    d->gpu_plan = std::move(fresh);  // not ready if this proof left the recorded plan half way: the next one records again
+  }
+  cells.reserve(cells.size() + d->gpu_plan.host_cells.size());
+  for (const CellBinding &c : d->gpu_plan.host_cells) {
+    if (!V.known(c.var)) throw UnsatisfiedError("target has no value: wire cell");
+    cells.push_back(lcp2_cell{c.row, c.col, V.val[c.var]});
   }
   const auto t_scatter = now();
   rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);

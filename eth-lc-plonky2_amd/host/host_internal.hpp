@@ -75,6 +75,22 @@ struct HostLanes {
   unsigned lanes = 1;
 };
 
+// What generate_witness_gpu learns at the first proof of a circuit and reuses afterwards (the structure of a witness generation -
+// which hashes are ready together, where their message words come from, which bound cells the host writes - does not depend on
+// the witness values; plonky2 builds the same kind of tables in build()):
+struct ShaBatchPlan {
+  std::vector<lcp2_sha_job> jobs;            // in device order (by level); in_src >= 0: index into the batch's word list
+  std::vector<uint32_t> word_vars;           // variable (root) whose value is word k of the batch
+  std::vector<uint32_t> level_start;
+  std::vector<std::array<uint32_t, 8>> out;  // digest variables of job k
+  size_t ops_left = 0;                       // SHA generators still waiting after this batch
+};
+struct GpuWitnessPlan {
+  bool ready = false;
+  std::vector<ShaBatchPlan> batches;
+  std::vector<CellBinding> host_cells;       // the bound cells of the rows the host writes cell by cell (var = root)
+};
+
 struct CircuitData::Impl {
   CircuitConfig config;
   uint32_t nrows = 0;                     // used rows (before padding)
@@ -89,6 +105,7 @@ struct CircuitData::Impl {
   lcp2_circuit *gpu = nullptr;
   lcp2_circuit *verifier = nullptr;
   HostLanes host_lanes;                   // planned at the first prove
+  GpuWitnessPlan gpu_plan;
   uint32_t find(uint32_t v) const { while (parent[v] != v) v = parent[v]; return v; }
 };
 
