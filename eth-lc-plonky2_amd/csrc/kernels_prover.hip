@@ -457,7 +457,56 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// The constraint combination of a generated gate, sum_j alpha^(m-1-j) c_j (the Horner chain of a program that lists its constraints
+// last to first), without a multiply-REDUCE per constraint: alpha^e comes from a table as three 22-bit limbs, a constraint value
+// (any u64: it need not even be canonical) is two 32-bit halves, and each of the six half x limb products - below 2^54 - is one
+// v_mad_u64_u32 into a 64-bit column sum that 128 terms cannot overflow.  12 instructions per constraint and two challenges
+// instead of 40; the columns are folded (sum_l (col_l + col_(3+l) 2^32) 2^(22 l) mod p) once per point.
+struct QTerms {
+  u64 col[QUOTIENT_MAX_CH][6];
+  u32 CH;
+  __device__ __forceinline__ void init(u32 ch) {
+    CH = ch;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+#pragma unroll
+      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
+  }
+  template <u32 E>  // x * alpha^E
+  __device__ __forceinline__ void add(const QuotientArgs &a, u64 x) {
+    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      if (c < CH) {
+        const_as<u32> L = konst(a.alpha_limbs) + ((size_t)c * QUOTIENT_TERM_POWS + E) * 4;
+#pragma unroll
+        for (u32 l = 0; l < 3; l++) {
+          const u32 w = L[l];
+          col[c][l] += (u64)x0 * w;
+          col[c][3 + l] += (u64)x1 * w;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void fold_into(QEmit &emit) const {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      if (c < CH) {
+        u64 v[3];
+#pragma unroll
+        for (u32 l = 0; l < 3; l++) {  // col_l + col_(3+l) 2^32 as a 128-bit value
+          const u64 lo = col[c][l] + (col[c][3 + l] << 32);
+          const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
+          v[l] = gl_reduce128(lo, hi);
+        }
+        emit.acc[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
+      }
+    }
+  }
+};
 }  // namespace lcp2
+
 #include "generated_gates.hpp"
 namespace lcp2 {
 static_assert(Q_GENERATED_COUNT == QUOTIENT_GENERATED_GATES, "prover_kernels.hpp and generated_gates.hpp disagree");

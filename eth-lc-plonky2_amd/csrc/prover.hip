@@ -39,7 +39,7 @@ struct lcp2_circuit {
   lcp2_oracle cs;  // constants_sigmas commitment
   // device: per-proof workspace (allocated once)
   lcp2_oracle wires, zs, quot;
-  DevBuf wires_vals, zs_vals, chunk_q, row_tot, scan_tmp, qvals, planes, small, partial, tables;
+  DevBuf wires_vals, zs_vals, chunk_q, row_tot, scan_tmp, qvals, planes, small, partial, tables, alpha_limbs;
   DevBuf fri_c[2];                       // ping-pong coefficient planes [2][m]
   std::vector<DevBuf> fri_vals, fri_dig; // per layer: value planes [2][8 m_l], digests
   std::vector<std::vector<u64>> fri_level_off;
@@ -97,6 +97,21 @@ int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
   bool unsupported;
   if (const char *why = params_problem(p, &unsupported)) return ctx->fail(unsupported ? LCP2_E_UNSUPPORTED : LCP2_E_INVALID, why);
   return LCP2_OK;
+}
+
+// alpha_c^e, e < QUOTIENT_TERM_POWS, as three 22-bit limbs (QuotientArgs::alpha_limbs)
+std::vector<uint32_t> alpha_limb_table(const u64 *alphas, u32 CH) {
+  std::vector<uint32_t> t((size_t)QUOTIENT_MAX_CH * QUOTIENT_TERM_POWS * 4, 0);
+  for (u32 c = 0; c < CH; c++) {
+    u64 pw = 1;
+    const u64 al = gl_canon(alphas[c]);
+    for (u32 e = 0; e < QUOTIENT_TERM_POWS; e++) {
+      uint32_t *w = &t[((size_t)c * QUOTIENT_TERM_POWS + e) * 4];
+      w[0] = (uint32_t)(pw & 0x3FFFFF); w[1] = (uint32_t)((pw >> 22) & 0x3FFFFF); w[2] = (uint32_t)(pw >> 44);
+      pw = gl_mul(pw, al);
+    }
+  }
+  return t;
 }
 
 int upload(lcp2_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
@@ -226,10 +241,13 @@ static int check_native_gates(lcp2_circuit *c) {
     }
     hs[SMALL_CHECK] = ~0ull;
     LCP2_HIP(ctx, hipMemcpyAsync(c->small.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    const std::vector<uint32_t> limbs = alpha_limb_table(&hs[SMALL_ALPHAS], p.num_challenges);
+    LCP2_TRY(upload(ctx, c->alpha_limbs, limbs.data(), limbs.size() * 4));
     QuotientArgs a{};
     u64 *d_small = c->small.u();
     a.wires = dw.u(); a.consts = dc.u(); a.stride = cnt; a.count = cnt;
     a.alphas = d_small + SMALL_ALPHAS; a.alpha_inv = d_small + SMALL_ALPHA_INV; a.pis = d_small + SMALL_PI_HASH; a.gate_scale = d_small + SMALL_GATE_SCALE;
+    a.alpha_limbs = (const u32 *)c->alpha_limbs.p;
     a.imm = c->d_imm.u(); a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.stage_list = (const u32 *)c->d_stage.p;
     a.num_wires = p.num_wires; a.num_gates = (u32)c->gates.size(); a.num_selectors = c->num_selectors; a.num_constants = p.num_constants;
     a.num_challenges = p.num_challenges; a.num_regs = c->num_regs; a.rc = ctx->d_rc;
@@ -592,8 +610,11 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     }
     for (u32 i = 0; i < 4; i++) h[SMALL_PI_HASH - SMALL_ALPHAS + i] = gl_canon(pi_hash[i]);
     h[SMALL_CHECK - SMALL_ALPHAS] = ~0ull;
+    const std::vector<uint32_t> limbs = alpha_limb_table(alphas, CH);
+    LCP2_HIP(ctx, c->alpha_limbs.ensure(limbs.size() * 4));
+    LCP2_HIP(ctx, hipMemcpyAsync(c->alpha_limbs.p, limbs.data(), limbs.size() * 4, hipMemcpyHostToDevice, s));
     LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
-    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `h` is a stack-lifetime staging buffer
+    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `h` and `limbs` are stack-lifetime staging buffers
   }
   // ---- K6: quotient values on the coset, coset iNTT, chunking, commitment
   {
@@ -603,6 +624,7 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     a.points = ntt.shift_table(gl_root_of_unity(lgN), lgN, 0, false, GL_GENERATOR, ls, hs);
     a.k_is = c->d_kis.u(); a.betas = d_betas; a.gammas = d_gammas; a.alphas = d_alphas; a.pis = d_small + SMALL_PI_HASH; a.imm = c->d_imm.u();
     a.alpha_inv = d_small + SMALL_ALPHA_INV; a.gate_scale = d_small + SMALL_GATE_SCALE; a.alpha_pow = d_small + SMALL_ALPHA_POW;
+    a.alpha_limbs = (const u32 *)c->alpha_limbs.p;
     a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.out = c->qvals.u();
     a.stage_list = (const u32 *)c->d_stage.p; a.num_wires = W; a.use_native = 1; a.rc = ctx->d_rc;
     a.N = N; a.lgN = lgN; a.rate_bits = p.rate_bits; a.num_gates = NG; a.num_selectors = c->num_selectors;

@@ -16,6 +16,7 @@ constexpr u32 QUOTIENT_MAX_CH = 2;
 // instead of one per operand (the interpreter executes one instruction at a time, so an operand load cannot overlap anything).
 constexpr u32 QUOTIENT_STAGE = 12;
 constexpr u32 QUOTIENT_ALPHA_POWS = 32; // >= CH + CH * PERM_MAX_CHUNKS + 1 exponents
+constexpr u32 QUOTIENT_TERM_POWS = 128; // alpha^e, e < 128, as 22-bit limbs: the constraint weights of the generated gates (at most 128 constraints)
 constexpr u32 QUOTIENT_GENERATED_GATES = 4;  // programs in csrc/generated_gates.hpp (static_assert-ed against the file)
 constexpr u32 QOP_LDG = 10;      // w0 = 10 | count << 8, w1 = offset into stage_list
 constexpr u32 QKIND_STAGE = 5;   // operand = staging slot idx
@@ -52,6 +53,9 @@ struct QuotientArgs {
   u32 use_native;          // 1: gates flagged LCP2_GATE_NATIVE_* run their native evaluator, 0: everything is interpreted
   const u64 *rc;           // Poseidon round constants (native PoseidonGate evaluator)
   const u64 *alpha_pow;    // [QUOTIENT_MAX_CH][QUOTIENT_ALPHA_POWS] alpha_c^e: weights of the permutation-term blocks
+  const u32 *alpha_limbs;  // [QUOTIENT_MAX_CH][QUOTIENT_TERM_POWS][4]: alpha_c^e cut into three 22-bit limbs (+ one word of padding): a
+                           // generated gate adds constraint x limbs into six 64-bit column sums per challenge, one multiply-accumulate
+                           // each and no reduction, and folds the columns once per point (kernels_prover.hip QTerms)
   const u64 *alpha_inv;    // [CH], 0 where alpha = 0
   const u64 *gate_scale;   // [num_gates][QUOTIENT_MAX_CH] alpha^(num_constraints - 1)
   const u32 *code;
