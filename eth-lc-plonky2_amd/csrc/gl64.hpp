@@ -188,6 +188,12 @@ LCP2_HD u64 gl_add_nc(u64 a, u64 b) {
   return s < a ? s + GL_EPS : s;
 }
 
+// a: any u64, b: canonical -> a - b, lazy (a - b + 2^64 = a - b + eps (mod p) on borrow, and then >= 2^32: no second borrow)
+LCP2_HD u64 gl_sub_nc(u64 a, u64 b) {
+  u64 d = a - b;
+  return a < b ? d - GL_EPS : d;
+}
+
 LCP2_HD u64 gl_mul(u64 a, u64 b) { return gl_canon(gl_mul_nc(a, b)); }
 LCP2_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 

@@ -302,9 +302,66 @@ __device__ u64 q_sbox(u64 x);
 // The running combination of a gate's constraints.  acc is kept LAZY (any u64 congruent to the value): a Horner step is a
 // 17-instruction multiply-reduce plus a 3-instruction add of the canonical constraint value, instead of 21 + 8 for canonical
 // arithmetic; whoever reads acc multiplies it with gl_mul, which accepts any u64 and returns a canonical value.
+// The constraint combination of a native gate, sum_j alpha^(e_j) c_j, without a multiply-REDUCE per constraint (a Horner chain
+// costs 17 + 3 instructions per constraint and challenge): alpha^e comes from a table as three 22-bit limbs, a constraint value
+// (any u64: it need not even be canonical) is two 32-bit halves, and each of the six half x limb products - below 2^54 - is one
+// v_mad_u64_u32 into a 64-bit column sum that 128 terms cannot overflow.  12 instructions per constraint and two challenges
+// instead of 40; the columns are folded (sum_l (col_l + col_(3+l) 2^32) 2^(22 l) mod p) once per point.
+struct QTerms {
+  u64 col[QUOTIENT_MAX_CH][6];
+  u32 CH;
+  __device__ __forceinline__ void init(u32 ch) {
+    CH = ch;
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+#pragma unroll
+      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
+  }
+  template <u32 E>  // x * alpha^E
+  __device__ __forceinline__ void add(const QuotientArgs &a, u64 x) {
+    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
+    add(a, E, x);
+  }
+  __device__ __forceinline__ void add(const QuotientArgs &a, u32 e /* wave-uniform, < QUOTIENT_TERM_POWS */, u64 x) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      if (c < CH) {
+        const_as<u32> L = konst(a.alpha_limbs) + ((size_t)c * QUOTIENT_TERM_POWS + e) * 4;
+#pragma unroll
+        for (u32 l = 0; l < 3; l++) {
+          const u32 w = L[l];
+          col[c][l] += (u64)x0 * w;
+          col[c][3 + l] += (u64)x1 * w;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void fold(u64 out[QUOTIENT_MAX_CH]) const {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      if (c < CH) {
+        u64 v[3];
+#pragma unroll
+        for (u32 l = 0; l < 3; l++) {  // col_l + col_(3+l) 2^32 as a 128-bit value
+          const u64 lo = col[c][l] + (col[c][3 + l] << 32);
+          const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
+          v[l] = gl_reduce128(lo, hi);
+        }
+        out[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
+      }
+    }
+  }
+};
+// (an evaluator that uses the weighted terms never touches acc / step until finish_terms(): the compiler keeps only what is used)
 struct QEmit {
   u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
   u32 CH, emitted;
+  bool weighted = false;  // acc is the finished combination sum_j alpha^j c_j (no rescaling by the caller)
+  QTerms t;
+  __device__ __forceinline__ void begin_terms() { t.init(CH); }
+  __device__ __forceinline__ void term(const QuotientArgs &a, u32 e, u64 x) { t.add(a, e, x); }  // x alpha^e; x any u64
+  __device__ __forceinline__ void finish_terms() { t.fold(acc); weighted = true; }
   __device__ __forceinline__ void operator()(u64 x) {  // forward gates: Horner with 1 / alpha (step = 0 encodes alpha = 0)
 #pragma unroll
     for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
@@ -320,6 +377,10 @@ struct QEmit {
 __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {
   const PosK k = pos_consts();
   const_as<u64> rc = konst(a.rc);
+  // the constraints come first to last: constraint j has the weight alpha^j (QTerms; no 1 / alpha, no rescaling)
+  QEmit &E = emit;
+  E.begin_terms();
+  auto emit_term = [&](u64 x) { E.term(a, E.emitted++, x); };
   const u64 *W = a.wires + i;
   const u64 st = a.stride;
   u64 in[12], dl[4], swap;
@@ -328,9 +389,9 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
   swap = W[24 * st];
 #pragma unroll
   for (int j = 0; j < 4; j++) dl[j] = W[(u64)(25 + j) * st];
-  emit(gl_sub(gl_mul(swap, swap), swap));
+  emit_term(gl_mul_nc(swap, gl_sub(swap, 1)));
 #pragma unroll
-  for (int j = 0; j < 4; j++) emit(gl_sub(gl_mul(swap, gl_sub(in[j + 4], in[j])), dl[j]));
+  for (int j = 0; j < 4; j++) emit_term(gl_sub_nc(gl_mul_nc(swap, gl_sub(in[j + 4], in[j])), dl[j]));
   u32 lo[12], hi[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) {
@@ -344,7 +405,7 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
     for (int j = 0; j < 12; j++) w[j] = W[(u64)(first_wire + j) * st];
 #pragma unroll
     for (int j = 0; j < 12; j++) {
-      emit(gl_sub(gl_canon(((u64)hi[j] << 32) | lo[j]), w[j]));
+      emit_term(gl_sub_nc(((u64)hi[j] << 32) | lo[j], w[j]));
       lo[j] = (u32)w[j]; hi[j] = (u32)(w[j] >> 32);
     }
   };
@@ -372,7 +433,7 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
   };
   auto constrain0 = [&](u32 r, u32 &ul, u32 &uh) {  // element 0 - S-box wire of partial round r; element 0 <- the wire
     const u64 w = lds[(r % QUOTIENT_STAGE) * T + tid];
-    emit(gl_sub(gl_canon(((u64)uh << 32) | ul), w));
+    emit_term(gl_sub_nc(((u64)uh << 32) | ul, w));
     ul = (u32)w; uh = (u32)(w >> 32);
   };
   u32 r = 0;
@@ -409,7 +470,8 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
 #pragma unroll
   for (int j = 0; j < 12; j++) out[j] = W[(u64)(12 + j) * st];
 #pragma unroll
-  for (int j = 0; j < 12; j++) emit(gl_sub(gl_canon(((u64)hi[j] << 32) | lo[j]), out[j]));
+  for (int j = 0; j < 12; j++) emit_term(gl_sub_nc(((u64)hi[j] << 32) | lo[j], out[j]));
+  E.finish_terms();
 }
 #endif
 
@@ -420,6 +482,7 @@ __device__ __forceinline__ void q_arithmetic_native(const QuotientArgs &a, u64 i
   const u64 *W = a.wires + i;
   const u64 st = a.stride;
   const u64 c0 = a.consts[(u64)a.num_selectors * st + i], c1 = a.consts[(u64)(a.num_selectors + 1) * st + i];
+  emit.begin_terms();  // operation k is constraint k: weight alpha^k
   for (int top = (int)num_ops; top > 0; top -= 4) {  // operations [top - 4, top), clamped at 0
     const int first = top >= 4 ? top - 4 : 0;
     u64 w[16];
@@ -429,10 +492,11 @@ __device__ __forceinline__ void q_arithmetic_native(const QuotientArgs &a, u64 i
     for (int k = 3; k >= 0; k--) {
       if (first + k < top) {
         const u64 comp = gl_add(gl_mul(gl_mul(w[4 * k], w[4 * k + 1]), c0), gl_mul(w[4 * k + 2], c1));
-        emit.horner(gl_sub(w[4 * k + 3], comp));  // listed last to first: plain Horner with alpha (alpha = 0 keeps the LAST one, c_0)
+        emit.term(a, (u32)(first + k), gl_sub(w[4 * k + 3], comp));
       }
     }
   }
+  emit.finish_terms();
 }
 // ---- native BaseSumGate<2> { num_limbs } (gates/base_sum.rs): constraints [sum_i 2^i limb_i - wire_0, limb_i^2 - limb_i ...],
 // folded last to first: the limb constraints from the top limb down (the recomposition is the same walk), then the sum.
@@ -440,6 +504,7 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
   const u64 *W = a.wires + i;
   const u64 st = a.stride;
   u64 sum = 0;
+  emit.begin_terms();  // constraint 0 is the sum, constraint 1 + l the booleanity of limb l
   for (int top = (int)num_limbs; top > 0; top -= 16) {  // limbs [top - 16, top) = wires [top - 15, top]
     u64 w[16];
 #pragma unroll
@@ -447,64 +512,17 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       if (top - 1 - j >= 0) {
-        emit.horner(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        emit.term(a, (u32)(top - j), gl_mul_nc(w[j], gl_sub(w[j], 1)));  // limb top - 1 - j
         sum = gl_add(gl_add(sum, sum), w[j]);
       }
     }
   }
-  emit.horner(gl_sub(sum, W[0]));
+  emit.term(a, 0, gl_sub(sum, W[0]));
+  emit.finish_terms();
 }
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The constraint combination of a generated gate, sum_j alpha^(m-1-j) c_j (the Horner chain of a program that lists its constraints
-// last to first), without a multiply-REDUCE per constraint: alpha^e comes from a table as three 22-bit limbs, a constraint value
-// (any u64: it need not even be canonical) is two 32-bit halves, and each of the six half x limb products - below 2^54 - is one
-// v_mad_u64_u32 into a 64-bit column sum that 128 terms cannot overflow.  12 instructions per constraint and two challenges
-// instead of 40; the columns are folded (sum_l (col_l + col_(3+l) 2^32) 2^(22 l) mod p) once per point.
-struct QTerms {
-  u64 col[QUOTIENT_MAX_CH][6];
-  u32 CH;
-  __device__ __forceinline__ void init(u32 ch) {
-    CH = ch;
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-#pragma unroll
-      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
-  }
-  template <u32 E>  // x * alpha^E
-  __device__ __forceinline__ void add(const QuotientArgs &a, u64 x) {
-    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      if (c < CH) {
-        const_as<u32> L = konst(a.alpha_limbs) + ((size_t)c * QUOTIENT_TERM_POWS + E) * 4;
-#pragma unroll
-        for (u32 l = 0; l < 3; l++) {
-          const u32 w = L[l];
-          col[c][l] += (u64)x0 * w;
-          col[c][3 + l] += (u64)x1 * w;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void fold_into(QEmit &emit) const {
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      if (c < CH) {
-        u64 v[3];
-#pragma unroll
-        for (u32 l = 0; l < 3; l++) {  // col_l + col_(3+l) 2^32 as a 128-bit value
-          const u64 lo = col[c][l] + (col[c][3 + l] << 32);
-          const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
-          v[l] = gl_reduce128(lo, hi);
-        }
-        emit.acc[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
-      }
-    }
-  }
-};
 }  // namespace lcp2
 
 #include "generated_gates.hpp"
@@ -572,7 +590,7 @@ __device__ __forceinline__ void q_gate_value(const QuotientArgs &a, u32 g, const
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
     if (c < CH) {
-      const u64 sum = (fwd && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
+      const u64 sum = (fwd && !emit.weighted && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
       val[c] = gl_mul(f, sum);
     }
 #endif
@@ -739,6 +757,7 @@ __device__ __forceinline__ void q_arith_base_pair(const QuotientArgs &a, u64 i, 
   eA.CH = eB.CH = CH; eA.emitted = eB.emitted = 0;
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { eA.acc[c] = eB.acc[c] = 0; eA.step[c] = eB.step[c] = c < CH ? konst(a.alphas)[c] : 0; }
+  eA.begin_terms(); eB.begin_terms();
   const int num_ops = (int)GA.num_constraints, num_limbs = (int)GB.num_constraints - 1;
   const u64 *W = a.wires + i;
   const u64 st = a.stride;
@@ -753,20 +772,21 @@ __device__ __forceinline__ void q_arith_base_pair(const QuotientArgs &a, u64 i, 
     for (int kk = 3; kk >= 0; kk--) {
       if ((hi - 16) / 4 + kk < num_ops) {
         const u64 comp = gl_add(gl_mul(gl_mul(w[4 * kk], w[4 * kk + 1]), c0), gl_mul(w[4 * kk + 2], c1));
-        eA.horner(gl_sub(w[4 * kk + 3], comp));
+        eA.term(a, (u32)((hi - 16) / 4 + kk), gl_sub(w[4 * kk + 3], comp));
       }
     }
 #pragma unroll
     for (int j = 15; j >= 0; j--) {
       const int limb = hi - 16 + j - 1;  // wire 0 is the sum, limb l sits on wire l + 1
       if (limb >= 0 && limb < num_limbs) {
-        eB.horner(gl_sub(gl_mul(w[j], w[j]), w[j]));
+        eB.term(a, (u32)(1 + limb), gl_mul_nc(w[j], gl_sub(w[j], 1)));
         sum = gl_add(gl_add(sum, sum), w[j]);
       }
     }
     if (hi == 16) w0 = w[0];
   }
-  eB.horner(gl_sub(sum, w0));
+  eB.term(a, 0, gl_sub(sum, w0));
+  eA.finish_terms(); eB.finish_terms();
   const u64 fA = q_filter(a, GA, i), fB = q_filter(a, GB, i);
 #pragma unroll
   for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
