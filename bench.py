@@ -248,9 +248,11 @@ def launch(a):
 
 def cpu_baseline(sample_bits, degree_bits):
     """Oracle prove() on a 2^sample_bits-row circuit of the same gate set, on min(32, cores) OpenMP threads (the reference's
-    published figure is for 32 vCPU, README.md:71), scaled linearly in the row count to 2^degree_bits.  Linear scaling
-    flatters the CPU: the NTTs grow as n log n and the working set leaves the caches."""
+    published figure is for 32 vCPU, README.md:71), scaled to 2^degree_bits: the transforms (measured separately on the sample: the
+    oracle's LDE of the 135 wire columns, x 1.4 for the Z / quotient / FRI columns) as n log n, everything else linearly in the row
+    count.  A 2^20-row sample would take ~2.5 minutes on the box, too long for the default run; 2^18 takes ~35 s."""
     import ctypes
+    import numpy as np
     import eth_lc_plonky2_amd as m
     import oracle_lib
     L = oracle_lib.load()
@@ -269,10 +271,20 @@ def cpu_baseline(sample_bits, degree_bits):
     dt = time.perf_counter() - t0
     assert oc.verify(proof, pis) == 0
     oc.close()
-    scale = float(1 << (degree_bits - sample_bits))
-    return {"value": 3600.0 / (dt * scale), "unit": "proofs/hr", "cores": threads, "kind": "port",
-            "sample": "oracle prove() of the same gate set at 2^%d rows: %.2f s on %d OpenMP threads, scaled x%d (linear in rows) to 2^%d"
-                      % (sample_bits, dt, threads, int(scale), degree_bits)}
+    n = 1 << sample_bits
+    cols = np.ascontiguousarray(wires[:, :] % np.uint64(m.GOLDILOCKS_P))
+    lde = np.zeros((cols.shape[0], n << params.rate_bits), dtype=np.uint64)
+    t0 = time.perf_counter()
+    L.orc_lde_batch(oracle_lib.vp(cols), cols.shape[0], n, params.rate_bits, 7, oracle_lib.vp(lde))
+    t_ntt = min(1.4 * (time.perf_counter() - t0), 0.9 * dt)
+    del lde
+    lg_s, lg_d = sample_bits + params.rate_bits, degree_bits + params.rate_bits
+    rows = float(1 << (degree_bits - sample_bits))
+    est = rows * ((dt - t_ntt) + t_ntt * lg_d / lg_s)
+    return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port",
+            "sample": "oracle prove() of the same gate set at 2^%d rows: %.2f s on %d OpenMP threads, of which transforms ~%.2f s; scaled to 2^%d rows "
+                      "(transforms x%d x %d/%d for n log n, the rest x%d): %.0f s per proof"
+                      % (sample_bits, dt, threads, t_ntt, degree_bits, int(rows), lg_d, lg_s, int(rows), est)}
 
 
 def main():

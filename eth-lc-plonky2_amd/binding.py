@@ -99,6 +99,7 @@ def load_library():
         "lcp2_device_count": (c.c_int, []),
         "lcp2_params_standard": (c.c_int, [c.c_uint32, c.c_uint32, c.POINTER(Params)]),
         "lcp2_ctx_create": (c.c_int, [c.c_int, c.c_void_p, c.POINTER(c.c_void_p)]),
+        "lcp2_ctx_create_ex": (c.c_int, [c.c_int, c.c_void_p, c.c_uint32, c.POINTER(c.c_void_p)]),
         "lcp2_ctx_destroy": (None, [c.c_void_p]),
         "lcp2_ctx_sync": (c.c_int, [c.c_void_p]),
         "lcp2_last_error": (c.c_char_p, [c.c_void_p]),
@@ -226,12 +227,14 @@ class Oracle:
 class Context:
     """One prover context = one GPU + one HIP stream (lcp2_ctx).  stream: a raw hipStream_t, or None / 0 for a private
     non-blocking stream - torch.cuda.current_stream().cuda_stream is 0 for the default stream, so work queued there (a fill, an
-    upload) is NOT ordered before the library's kernels: torch.cuda.synchronize() first, ctx.sync() before reading results."""
+    upload) is NOT ordered before the library's kernels: torch.cuda.synchronize() first, ctx.sync() before reading results - or
+    pass order_with_default_stream=True (LCP2_CTX_ORDER_WITH_DEFAULT_STREAM): the private stream is then an ordinary blocking
+    stream, which the runtime orders against stream 0 in both directions."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, order_with_default_stream=False):
         self.lib = load_library()
         h = ctypes.c_void_p()
-        rc = self.lib.lcp2_ctx_create(device, stream, ctypes.byref(h))
+        rc = self.lib.lcp2_ctx_create_ex(device, stream, 1 if order_with_default_stream else 0, ctypes.byref(h))
         if rc:
             raise Lcp2Error(rc, self.lib.lcp2_status_str(rc).decode())
         self.handle = h

@@ -44,9 +44,11 @@ extern "C" int lcp2_params_standard(uint32_t degree_bits, uint32_t num_constants
 }
 
 // ------------------------------------------------------------------ context
-extern "C" int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out) {
+extern "C" int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out) { return lcp2_ctx_create_ex(device, stream, 0, out); }
+extern "C" int lcp2_ctx_create_ex(int device, void *stream, uint32_t flags, lcp2_ctx **out) {
   if (!out) return LCP2_E_INVALID;
   *out = nullptr;
+  if ((flags & ~LCP2_CTX_ORDER_WITH_DEFAULT_STREAM) || ((flags & LCP2_CTX_ORDER_WITH_DEFAULT_STREAM) && stream)) return LCP2_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LCP2_E_NODEVICE;
   if (device < 0 || device >= ndev) return LCP2_E_INVALID;
@@ -56,7 +58,8 @@ extern "C" int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out) {
   if (stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LCP2_E_HIP; }
+    const unsigned how = (flags & LCP2_CTX_ORDER_WITH_DEFAULT_STREAM) ? hipStreamDefault : hipStreamNonBlocking;
+    if (hipStreamCreateWithFlags(&ctx->stream, how) != hipSuccess) { delete ctx; return LCP2_E_HIP; }
     ctx->own_stream = true;
   }
   u64 rc[POS_RC_WORDS];  // the 360 round constants, then the group constants of the partial rounds (poseidon.hpp)

@@ -89,6 +89,12 @@ int lcp2_device_count(void);
  * synchronise the producer of a device buffer before handing it over, and lcp2_ctx_sync before consuming results elsewhere.
  * Every entry point that returns host data has synchronised the context's stream when it returns. */
 int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out);
+/* The same with flags.  LCP2_CTX_ORDER_WITH_DEFAULT_STREAM (stream must be NULL): the private stream is created as a BLOCKING
+ * stream (hipStreamDefault), i.e. it orders itself against the legacy default stream in both directions the way any ordinary
+ * stream does - the choice for a caller whose other work runs on stream 0 (PyTorch's default stream) and who does not want to
+ * place explicit synchronisations around the library's calls.  0 = lcp2_ctx_create. */
+#define LCP2_CTX_ORDER_WITH_DEFAULT_STREAM 1u
+int lcp2_ctx_create_ex(int device, void *stream, uint32_t flags, lcp2_ctx **out);
 void lcp2_ctx_destroy(lcp2_ctx *ctx);
 int lcp2_ctx_sync(lcp2_ctx *ctx);
 const char *lcp2_last_error(lcp2_ctx *ctx);

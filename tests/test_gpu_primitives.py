@@ -2,6 +2,7 @@
 (include/lcp2.h) and is compared bit for bit with the oracle on the same seeded inputs."""
 import hashlib
 import json
+import ctypes
 import os
 
 import numpy as np
@@ -266,3 +267,29 @@ def test_poseidon_single_wave_batches(gpu_ctx, oracle, count):
         want = np.zeros_like(s)
         oracle.orc_poseidon_permute_batch(vp(s), vp(want), count)
         assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_context_ordered_with_the_default_stream():
+    """LCP2_CTX_ORDER_WITH_DEFAULT_STREAM: work queued on stream 0 (torch's default stream) right before a library call, with no
+    synchronisation in between, is seen by the library's kernels; and torch reads the result right after, again without one"""
+    import torch
+    import eth_lc_plonky2_amd as m
+    ctx = m.Context(0, order_with_default_stream=True)
+    lg, ncols = 18, 8
+    n = 1 << lg
+    rng = np.random.default_rng(3)
+    host = rng.integers(0, m.GOLDILOCKS_P, size=(ncols, n), dtype=np.uint64)
+    for trial in range(5):
+        buf = torch.zeros((ncols, n), dtype=torch.int64, device="cuda")
+        src = torch.from_numpy(host.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        buf.copy_(src)                         # on stream 0, not synchronised
+        ctx._check(ctx.lib.lcp2_ntt_batch(ctx.handle, ctypes.c_void_p(buf.data_ptr()), ncols, lg, 0, 1, m.MEM_DEVICE))   # forward
+        ctx._check(ctx.lib.lcp2_ntt_batch(ctx.handle, ctypes.c_void_p(buf.data_ptr()), ncols, lg, 1, 1, m.MEM_DEVICE))   # and back
+        back = buf.clone()                     # on stream 0 again, no ctx.sync()
+        torch.cuda.synchronize()
+        assert (back.cpu().numpy().view(np.uint64) == host).all()
+    ctx.close()
+    with pytest.raises(m.Lcp2Error):
+        m.Context(0, stream=torch.cuda.Stream().cuda_stream, order_with_default_stream=True)  # the flag is for the private stream only
