@@ -12,5 +12,6 @@ from . import binding  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402
 from . import poseidon_py  # noqa: F401,E402
 from . import recursion_gates  # noqa: F401,E402
+from . import u32_gates  # noqa: F401,E402
 from . import batch  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402

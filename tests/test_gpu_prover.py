@@ -451,3 +451,31 @@ def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
     assert e.value.status == -5  # LCP2_E_UNSAT
     data.close()
     oc.close()
+
+
+@pytest.mark.parametrize("degree_bits", [6, 9])
+def test_reference_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
+    """a circuit of the gates the reference's own circuit is made of (u32_gates.py: plonky2_u32's U32 arithmetic / add-many /
+    subtraction / range-check gates, ComparisonGate, plonky2's CosetInterpolationGate - degree-4 and degree-8 constraints, three
+    selector groups - all interpreted by K6): the GPU proof equals the oracle's word for word and verifies; a broken row is
+    LCP2_E_UNSAT"""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import u32_gates as ug
+    params = m.standard_params(degree_bits, 5)
+    circ, wires, pis = ug.reference_gates_circuit(params, seed=60 + degree_bits)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    want = oc.prove(wires, pis)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    got = data.prove(wires, pis)
+    assert _first_mismatch(m, params, got, want) is None, _first_mismatch(m, params, got, want)
+    data.verify(got, pis)
+    assert oc.verify(got, pis) == 0
+    kinds = list(ug.ROW_GENERATORS)
+    for kind, wire in (("U32ArithmeticGate", 3), ("ComparisonGate", 2), ("CosetInterpolationGate", 35), ("U32SubtractionGate", 4)):
+        w2 = wires.copy()
+        w2[wire, kinds.index(kind)] ^= np.uint64(1)
+        with pytest.raises(m.Lcp2Error) as e:
+            data.prove(w2, pis)
+        assert e.value.status == -5, kind  # LCP2_E_UNSAT
+    data.close()
+    oc.close()

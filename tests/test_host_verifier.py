@@ -286,6 +286,63 @@ def test_recursion_gate_programs(oracle):
     vd.close()
 
 
+def test_reference_gate_programs(oracle):
+    """The gates the reference's circuit is really made of (u32_gates.py: plonky2_u32's U32ArithmeticGate, U32AddManyGate,
+    U32SubtractionGate, U32RangeCheckGate, ComparisonGate and plonky2's CosetInterpolationGate; [RECALL], parity unpinned) as
+    programs: constraint counts as the gates' num_constraints() formulas, zero on rows filled by the matching generators (incl. the
+    corner cases: equal inputs of a comparison, the largest product of an arithmetic row), non-zero when a wire the gate constrains
+    is changed, and a circuit made of them proves (oracle) and verifies (product)."""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import u32_gates as ug
+    params = m.standard_params(6, 5)
+    circ, wires, pis = ug.reference_gates_circuit(params, seed=9)
+    gs = circ.gateset
+    assert gs.names == ["NoopGate", "ComparisonGate", "U32AddManyGate", "U32ArithmeticGate", "U32RangeCheckGate", "U32SubtractionGate",
+                        "CosetInterpolationGate"]
+    assert gs.num_selectors == 3
+    want = {"ComparisonGate": 6 + 5 * 16 + 2, "U32AddManyGate": 5 * (3 + 18), "U32ArithmeticGate": 3 * (4 + 32), "U32RangeCheckGate": 7 * 17,
+            "U32SubtractionGate": 6 * (3 + 16), "CosetInterpolationGate": 2 + 4 * 2 + 2}
+    for name, count in want.items():
+        assert gs.gates[gs.index(name)].num_constraints == count, name
+    # corner-case rows: a comparison of equal inputs, an arithmetic row with the largest possible product
+    rng = np.random.default_rng(1)
+    kinds = list(ug.ROW_GENERATORS)
+    wires[:, kinds.index("ComparisonGate")] = np.array(ug.row_comparison(rng, 135, equal=True), dtype=np.uint64)
+    wires[:, kinds.index("U32ArithmeticGate")] = np.array(ug.row_u32_arithmetic(rng, 135, force_high_max=True), dtype=np.uint64)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    bad, first = oc.check_witness(wires, pis)
+    assert bad == 0, first
+    # rows 0..5 hold one gate of each kind in the order of ROW_GENERATORS; per kind: wires whose change must break the row
+    row_of = {k: i for i, k in enumerate(kinds)}
+    cases = [("U32ArithmeticGate", w) for w in (0, 2, 3, 4, 5, 6 + 3, 18 + 0, 18 + 31, 18 + 32 + 17)] + \
+            [("U32AddManyGate", w) for w in (0, 3, 4, 5, 6 + 2, 30 + 0, 30 + 17, 30 + 18 * 4 + 16)] + \
+            [("U32SubtractionGate", w) for w in (0, 1, 2, 3, 4, 5 * 6 + 7, 30 + 16 * 5 + 15)] + \
+            [("U32RangeCheckGate", w) for w in (0, 6, 7, 7 + 16 * 6 + 15)] + \
+            [("ComparisonGate", w) for w in (0, 1, 2, 3, 4 + 5, 4 + 16 + 9, 4 + 48 + 2, 4 + 64 + 15, 4 + 80, 4 + 82)] + \
+            [("CosetInterpolationGate", w) for w in (0, 1, 32, 33, 35, 36, 37 + 3, 37 + 8, 46)]
+    for kind, wire in cases:
+        w2 = wires.copy()
+        w2[wire, row_of[kind]] = np.uint64((int(w2[wire, row_of[kind]]) + 1) % m.GOLDILOCKS_P)
+        bad, first = oc.check_witness(w2, pis)
+        assert bad > 0 and first[0] == row_of[kind], (kind, wire)
+    # wires a gate does not use are free
+    for kind, wire in (("U32RangeCheckGate", 7 + 16 * 7), ("ComparisonGate", 4 + 83), ("CosetInterpolationGate", 47), ("U32SubtractionGate", 30 + 16 * 6)):
+        w2 = wires.copy()
+        w2[wire, row_of[kind]] ^= np.uint64(5)
+        assert oc.check_witness(w2, pis)[0] == 0, (kind, wire)
+    proof = oc.prove(wires, pis)
+    assert oc.verify(proof, pis) == 0
+    digest, cap = oc.digest()
+    vd = m.CircuitData.verifier_only(circ, digest, cap)
+    vd.verify(proof, pis)
+    bad = proof.copy()
+    bad[3 * 64 + 9] ^= np.uint64(1)  # an opening
+    with pytest.raises(m.ProofRejected):
+        vd.verify(bad, pis)
+    oc.close()
+    vd.close()
+
+
 def test_proof_byte_serialisation_round_trip(oracle):
     """ProofWithPublicInputs <-> bytes (plonky2 util/serialization.rs layout, PARITY UNPINNED: the reference holds no serialised
     proof).  Round trip, exact size, u8 sibling counts where the layout says, and every malformed buffer is refused."""
