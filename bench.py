@@ -61,7 +61,7 @@ def valu_roofline(perms_per_s):
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench (tools/collect_profiles.sh)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench (tools/collect_profiles.sh)
 
 
 def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
