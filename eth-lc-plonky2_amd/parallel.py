@@ -300,9 +300,16 @@ class TorchComm:
                 self.ctx.buffer_write(buf, np.zeros(world * words_per_rank, dtype=np.uint64))
                 self.ctx.buffer_write(buf + 8 * rank * words_per_rank, want[rank * words_per_rank:(rank + 1) * words_per_rank])
                 before = self.bytes_gathered
-                self.all_gather_device(buf, world * words_per_rank, words_per_rank)
+                try:
+                    self.all_gather_device(buf, world * words_per_rank, words_per_rank)
+                    good = bool((self.ctx.buffer_read(buf, world * words_per_rank) == want).all())
+                except RuntimeError:
+                    # an argument check of the framework (the same on every rank: the ranks stay in step); anything raised
+                    # from inside the collective itself is not recoverable here and propagates from the staged attempt
+                    if self.staged:
+                        raise
+                    good = False
                 self.bytes_gathered = before
-                good = bool((self.ctx.buffer_read(buf, world * words_per_rank) == want).all())
                 # every rank must take the same decision: the collectives of the two forms differ
                 agreed = int(self.sum_host(np.array([0 if good else 1], dtype=np.uint64))[0]) == 0
                 if agreed:

@@ -250,6 +250,44 @@ sp.comm.all_gather_tensor(t, rank)
 assert t.tolist() == [10, 11, 12, 13, 20, 21, 22, 23]
 body = proof[192:]
 assert (body[20:30] == 555).all() and (body[30:40] == 556).all() and body[1] == body[0] + 1
+
+# TorchComm.self_check (what bench.py runs before the sharded proof): a known-answer all-gather on a library buffer; the in-place
+# form is kept when it works, the staged form is chosen - by every rank alike - when the in-place form returns wrong data or the
+# framework refuses it, and the check raises when neither form works
+class FakeCtx:  # "device" buffers are numpy arrays, addressed by their data pointer
+    def __init__(self): self.bufs = {}
+    def buffer_alloc(self, words):
+        a = np.zeros(words, dtype=np.uint64); self.bufs[a.ctypes.data] = a; return a.ctypes.data
+    def buffer_free(self, ptr): del self.bufs[ptr]
+    def _at(self, ptr, words):
+        for base, a in self.bufs.items():
+            if base <= ptr < base + 8 * a.size: return a[(ptr - base) // 8:(ptr - base) // 8 + words]
+        raise KeyError(ptr)
+    def buffer_write(self, ptr, arr): self._at(ptr, arr.size)[:] = arr
+    def buffer_read(self, ptr, words): return self._at(ptr, words).copy()
+    def sync(self): pass
+class CheckComm(m.parallel.TorchComm):
+    broken, refuse = False, False
+    def all_gather_device(self, ptr, total_words, words_per_rank):
+        view = torch.from_numpy(self.ctx._at(ptr, total_words).view(np.int64))
+        if not self.staged and self.refuse: raise RuntimeError("in-place all-gather refused")
+        self.all_gather_tensor(view, rank)
+        if not self.staged and self.broken and rank == 1: view[3] += 1   # the aliased form "returns wrong data" on one rank only
+        self.bytes_gathered += 8 * words_per_rank
+fc = FakeCtx()
+assert CheckComm(dist, None, fc).self_check(256) == "in-place"
+assert CheckComm(dist, None, fc, staged=True).self_check(256) == "staged"
+for attr in ("broken", "refuse"):
+    cc = CheckComm(dist, None, fc); setattr(cc, attr, True)
+    assert cc.self_check(256) == "staged" and cc.staged and cc.bytes_gathered == 0
+class Hopeless(CheckComm):
+    def all_gather_device(self, ptr, total_words, words_per_rank): pass     # gathers nothing in either form
+try:
+    Hopeless(dist, None, fc).self_check(64)
+    raise SystemExit("self_check accepted a collective that gathers nothing")
+except RuntimeError:
+    pass
+assert not fc.bufs  # every check buffer was freed
 dist.destroy_process_group()
 print("ok", rank)
 """
