@@ -10,10 +10,16 @@ layers, 16 PoW bits, 28 queries).  The circuit is the synthetic satisfiable one 
 eth-lc-plonky2_amd/circuit.py over plonky2's own gate set (NoopGate, ConstantGate, PublicInputGate,
 BaseSumGate<2>, ArithmeticGate, PoseidonGate as gate programs; the public inputs hashed in-circuit as
 circuit_builder.rs::build does; real copy constraints); the witness is resident in HBM when the timed region
-starts and the proof produced in the last step is checked by the verifier.  Two side fields carry the same
+starts and the proof produced in the last step is checked by the verifier.  Side fields carry the same
 prover on circuits built from the reference's own gadgets by the C++ host layer, device-side witness
-generation included: `config.real_lc_step` (updates 633 -> 634, 2^19 rows in the own SHA-256 layout) and
+generation included: `config.sync_committee_ssz` (BASELINE configs[1]: the SyncCommitteeSSZ gadget alone),
+`config.real_lc_step` (updates 633 -> 634, 2^19 rows in the own SHA-256 layout), `config.real_lc_step_recursive`
+(the same with the recursive verification of an inner proof that has the BLS proof's public inputs) and
 `config.real_gadget_circuit_2p22` (the step plus six more SyncCommitteeSSZ gadgets: 2.24 M gates, 2^22 rows).
+
+`--gpus N` without WORLD_SIZE in the environment: this process only LAUNCHES the N ranks (child processes of this script with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; it never imports torch or touches HIP), relays rank 0's line and passes a failing
+rank's exit code on.  With WORLD_SIZE set (torch.distributed.run) the process is a rank.
 
 N > 1: one rank per GPU, every rank proves its own witness of the same circuit (BASELINE configs[4],
 independent light-client updates: "replicas", no data-path collective) -> weak scaling; the only
@@ -21,7 +27,8 @@ collectives are the timing barrier and the max-reduce of the elapsed time.  Afte
 ranks prove ONE proof together, sharded by LDE coset with the witness arriving column-sharded (BASELINE
 configs[3]; eth-lc-plonky2_amd/parallel.py::ShardedProver over RCCL: all-gathers of the witness, its
 coefficients and the quotient planes, sum all-reduces of caps and proof shares); its wall time is reported
-beside the headline value as `config.sharded_proof` (a side field: `value` stays the replica throughput).
+beside the headline value as `config.sharded_proof` (`value` stays the replica throughput; a failure of the sharded proof is a
+non-zero exit code).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing, K4a):
 algorithmic bytes per launch / HIP-event time per launch measured inside this run.  `cpu_baseline` is the

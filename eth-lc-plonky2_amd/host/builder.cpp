@@ -741,7 +741,7 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
   const bool prof = getenv("LCP2_PROF") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  double t_host = 0, t_sha = 0;
+  double t_host = 0;
   if (d->host_lanes.lane_of_op.size() != d->ops.size()) {
     // One lane unless LCP2_HOST_LANES asks for more.  Measured on the light-client circuit with the recursive verifier (EPYC 9575F,
     // profiles/r03_host_witness.md): one lane 9.8 ms, eight lanes 8.4-9.5 ms with outliers of 17 ms - everything the verifier does
@@ -873,7 +873,6 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     printf("  witness generation %.2f ms: host generators %.2f ms on %u lane(s) (%zu sweeps, %zu visits of %zu ops, %zu PoseidonGate rows), SHA-256 batches %.2f ms, "
            "PoseidonGate rows on the device + cell list %.2f ms, scatter of %zu cells %.2f ms\n",
            ms(t_begin, now()), t_host, d->host_lanes.lanes, st.sweeps, st.visits, d->ops.size(), pos_rows.size(), ms(t_begin, t_rows) - t_host, ms(t_rows, t_scatter), cells.size(), ms(t_scatter, now()));
-  (void)t_sha;
   public_inputs.clear();
   for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
 }
