@@ -122,6 +122,20 @@ def test_emu_lde_headline_shape_takes_the_prefetching_kernel(oracle, emu, comput
     assert (lde == lde_leaf_order(oracle, x % np.uint64(P))).all()
 
 
+@pytest.mark.parametrize("computed_scale", [False, True])
+def test_emu_coset_forward_headline_shape(oracle, emu, computed_scale):
+    # the coset NTT (one coset: z = 0) through the strided prefetching pass with a factor: table (FMODE 1) and computed (FMODE 2)
+    lg, n = 22, 1 << 22
+    rng = np.random.default_rng(2230 + computed_scale)
+    x = rand_field(rng, (8, n))
+    out = np.zeros_like(x)
+    assert emu.emu_ntt_forward(vp(x), vp(out), lg, 8, 7, 0x100 if computed_scale else 0) == 2
+    perm = bitrev_perm(lg)
+    ref = x[3].copy()
+    oracle.orc_coset_fft(vp(ref), n, 7)
+    assert (out[3] == ref[perm]).all()
+
+
 def test_emu_plain_forward_headline_shape(oracle, emu):
     # the same shapes without a coset scale (FMODE 0): 8 columns are the fewest for which the launch takes the prefetching form
     lg, n = 22, 1 << 22

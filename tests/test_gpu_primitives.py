@@ -139,6 +139,28 @@ def test_ntt_three_pass_plans_parity(gpu_ctx, oracle, lg):
         assert int(v[0, i]) == pow(7 * pow(w, i, P), 3, P)
 
 
+def test_ntt_batch_headline_size_takes_the_prefetching_kernel(gpu_ctx, oracle):
+    """2^22 is the size whose passes have the shapes of the fused prefetching kernel (9 strided + 13 contiguous bits), and 8 columns
+    are the fewest for which a plain transform takes it: lcp2_ntt_batch forward without a shift (no factor), with the coset shift
+    (the computed scale with a single coset: z = 0) and back, two columns against the oracle's textbook transforms"""
+    lg, n, ncols = 22, 1 << 22, 8
+    rng = np.random.default_rng(2222)
+    x = rand_field(rng, (ncols, n), canonical=False)
+    xc = x % np.uint64(P)
+    got = gpu_ctx.ntt_batch(x)
+    for c in (0, 7):
+        want = xc[c].copy()
+        oracle.orc_fft(vp(want), n)
+        assert (got[c] == want).all()
+    assert (gpu_ctx.ntt_batch(got, inverse=True) == xc).all()
+    got = gpu_ctx.ntt_batch(x, shift=7)
+    for c in (1, 6):
+        want = xc[c].copy()
+        oracle.orc_coset_fft(vp(want), n, 7)
+        assert (got[c] == want).all()
+    assert (gpu_ctx.ntt_batch(got, inverse=True, shift=7) == xc).all()
+
+
 def test_sha256_tree_golden_roots(gpu_ctx, oracle):
     kat = json.load(open(os.path.join(G, "sha256_kat.json")))
     for n, root in kat["zero_leaf_merkle_roots"].items():
