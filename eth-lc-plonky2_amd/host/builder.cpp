@@ -766,7 +766,7 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     if (d->gpu_plan.ready && batch_no < d->gpu_plan.batches.size()) {
       // the batch as planned at the first proof: only the message words are fetched
       const ShaBatchPlan &B = d->gpu_plan.batches[batch_no];
-      bool applies = B.ops_left < sha_ops.size();
+      bool applies = B.ops_left.size() < sha_ops.size();
       std::vector<uint32_t> words(B.word_vars.size());
       for (size_t k = 0; k < words.size() && applies; k++) {
         if (!V.known(B.word_vars[k])) applies = false;
@@ -779,7 +779,8 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
         if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_sha256_witness: ") + lcp2_status_str(rc) + " (" + lcp2_last_error(d->ctx) + ")");
         for (size_t k = 0; k < B.jobs.size(); k++)
           for (int w = 0; w < 8; w++) V.set(B.out[k][w], digests[k * 8 + w], "sha256 digest");
-        sha_ops.resize(B.ops_left);  // only the count matters from here on: the next batch is planned too, or there is none
+        sha_ops.clear();
+        for (uint32_t k : B.ops_left) sha_ops.push_back(&d->ops[k]);
         continue;
       }
       d->gpu_plan = GpuWitnessPlan();  // another set of witness targets than at the first proof: plan afresh, from this batch on
@@ -836,7 +837,8 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       for (int w = 0; w < 8; w++) V.set(batch[s]->out8[w], digests[(size_t)newslot[s] * 8 + w], "sha256 digest");
     if (recording) {
       ShaBatchPlan B;
-      B.jobs = sorted; B.word_vars = word_vars; B.level_start = level_start; B.ops_left = later.size();
+      B.jobs = sorted; B.word_vars = word_vars; B.level_start = level_start;
+      for (const Op *op : later) B.ops_left.push_back((uint32_t)(op - d->ops.data()));
       B.out.resize(jobs.size());
       for (uint32_t s = 0; s < batch.size(); s++)
         for (int w = 0; w < 8; w++) B.out[newslot[s]][w] = d->find(batch[s]->out8[w]);

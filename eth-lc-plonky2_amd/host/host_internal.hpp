@@ -83,7 +83,7 @@ struct ShaBatchPlan {
   std::vector<uint32_t> word_vars;           // variable (root) whose value is word k of the batch
   std::vector<uint32_t> level_start;
   std::vector<std::array<uint32_t, 8>> out;  // digest variables of job k
-  size_t ops_left = 0;                       // SHA generators still waiting after this batch
+  std::vector<uint32_t> ops_left;            // the SHA generators still waiting after this batch (indices into Impl::ops)
 };
 struct GpuWitnessPlan {
   bool ready = false;
