@@ -16,6 +16,7 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 u32p = ctypes.POINTER(ctypes.c_uint32)
 u8p = ctypes.POINTER(ctypes.c_uint8)
 MEM_HOST, MEM_DEVICE = 0, 1
+E_UNSAT = -5
 SECTION_OPENINGS, SECTION_FRI_CAP0, SECTION_AFTER_CAPS = 0, 1, 2
 
 K_INTT, K_LDE, K_LEAF_HASH, K_MERKLE, K_PERM_Z, K_QUOTIENT, K_OPENINGS, K_FRI, K_POW, K_SHA256, K_OTHER = range(11)
@@ -117,6 +118,7 @@ def load_library():
         "lcp2_buffer_read": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_buffer_write": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_buffer_copy": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t]),
+        "lcp2_buffer_copy_2d": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_size_t, c.c_size_t]),
         "lcp2_commit_values": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_commit_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
         "lcp2_commit_cosets": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, c.c_int, c.POINTER(c.c_void_p), c.c_void_p]),
@@ -132,6 +134,10 @@ def load_library():
         "lcp2_prove": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]),
         "lcp2_commit_wires": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]),
         "lcp2_commit_wires_coeffs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_commit_wires_rows": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_perm_zs_rows_begin": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+        "lcp2_perm_zs_rows_finish": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_size_t)]),
+        "lcp2_perm_zs_commit": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_perm_zs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_quotient": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
         "lcp2_fri_open": (c.c_int, [c.c_void_p, c.c_void_p, c.POINTER(ChallengerState), c.c_void_p]),
@@ -355,6 +361,11 @@ class Context:
     def buffer_copy(self, dst_ptr, src_ptr, words):
         self._check(self.lib.lcp2_buffer_copy(self.handle, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), words * 8))
 
+    def buffer_copy_2d(self, dst_ptr, dst_pitch_words, src_ptr, src_pitch_words, width_words, height):
+        """`height` runs of `width_words`, the pitches apart (device to device)"""
+        self._check(self.lib.lcp2_buffer_copy_2d(self.handle, ctypes.c_void_p(dst_ptr), dst_pitch_words * 8, ctypes.c_void_p(src_ptr),
+                                                 src_pitch_words * 8, width_words * 8, height))
+
     # ---- timing
     def prof_enable(self, on=True):
         self._check(self.lib.lcp2_prof_enable(self.handle, int(on)))
@@ -565,6 +576,30 @@ class CircuitData:
         """commit_wires with the coefficients supplied (device pointers): the sharded proof's polynomial-parallel iNTT"""
         cap = self._cap()
         self._check(self.lib.lcp2_commit_wires_coeffs(self.handle, ctypes.c_void_p(wires_ptr), ctypes.c_void_p(coeffs_ptr), _ptr(cap)))
+        return cap
+
+    # row exchange form of a sharded proof (include/lcp2.h): the rank holds the witness values of its row block only
+    def commit_wires_rows(self, rows_ptr, coeffs_ptr):
+        cap = self._cap()
+        self._check(self.lib.lcp2_commit_wires_rows(self.handle, ctypes.c_void_p(rows_ptr), ctypes.c_void_p(coeffs_ptr), _ptr(cap)))
+        return cap
+
+    def perm_zs_rows_begin(self, betas, gammas, world):
+        """this rank's share of the table [world][num_challenges] of row-block products"""
+        out, b, g = np.zeros(world * self.circ.params.num_challenges, dtype=np.uint64), _np_u64(betas), _np_u64(gammas)
+        self._check(self.lib.lcp2_perm_zs_rows_begin(self.handle, _ptr(b), _ptr(g), _ptr(out)))
+        return out
+
+    def perm_zs_rows_finish(self, block_products):
+        """-> (device pointer, words) of the exchange buffer [world][columns][rows]; this rank's slot is filled"""
+        bp = _np_u64(block_products)
+        ptr, words = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self.lib.lcp2_perm_zs_rows_finish(self.handle, _ptr(bp), ctypes.byref(ptr), ctypes.byref(words)))
+        return ptr.value, words.value
+
+    def perm_zs_commit(self):
+        cap = self._cap()
+        self._check(self.lib.lcp2_perm_zs_commit(self.handle, _ptr(cap)))
         return cap
 
     def perm_zs(self, betas, gammas):

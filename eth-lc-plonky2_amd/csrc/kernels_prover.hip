@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_perm_chunks(PermArgs a) {
   u64 row = (u64)rb * blockDim.x + threadIdx.x;
   if (row >= a.n) return;
   const u64 beta = a.betas[ch], gamma = a.gammas[ch];
-  u64 x = two_level(a.subgroup, row);
+  u64 x = two_level(a.subgroup, a.row0 + row);
   u64 bx = gl_mul(beta, x);
   u64 pn[PERM_MAX_CHUNKS], pd[PERM_MAX_CHUNKS];
 #pragma unroll
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void k_perm_chunks(PermArgs a) {
     pn[k] = 1; pd[k] = 1;
     if (k < a.nchunks) {
       for (u32 j = k * a.chunk; j < a.num_routed && j < (k + 1) * a.chunk; j++) {
-        u64 w = gl_canon(a.wires[(u64)j * a.n + row]);
+        u64 w = gl_canon(a.wires[(u64)j * a.wires_stride + row]);
         u64 wg = gl_add(w, gamma);
         // lazy through the products (any u64 congruent to the element); the batch inversion below multiplies canonically
         pn[k] = gl_mul_nc(pn[k], gl_add_nc(gl_mul_nc(bx, a.k_is[j]), wg));
-        pd[k] = gl_mul_nc(pd[k], gl_add_nc(gl_mul_nc(beta, a.sigmas[(u64)j * a.n + row]), wg));
+        pd[k] = gl_mul_nc(pd[k], gl_add_nc(gl_mul_nc(beta, a.sigmas[(u64)j * a.sigma_stride + row]), wg));
       }
     }
   }
@@ -163,6 +163,10 @@ __global__ __launch_bounds__(256) void k_perm_finalize(PermArgs a) {
   u32 ch = blockIdx.y;
   if (row >= a.n) return;
   u64 acc = a.zs_out[(u64)ch * a.n + row];
+  if (a.prefix) {
+    acc = gl_mul(acc, a.prefix[ch]);
+    a.zs_out[(u64)ch * a.n + row] = acc;
+  }
   u32 npp = a.nchunks - 1;
   for (u32 k = 0; k < npp; k++) {
     acc = gl_mul(acc, a.chunk_q[((u64)ch * a.nchunks + k) * a.n + row]);

@@ -598,6 +598,14 @@ extern "C" int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_sr
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LCP2_OK;
 }
+extern "C" int lcp2_buffer_copy_2d(lcp2_ctx *ctx, void *dev_dst, size_t dst_pitch, const void *dev_src, size_t src_pitch, size_t width, size_t height) {
+  if (!ctx || !dev_dst || !dev_src || width > dst_pitch || width > src_pitch) return LCP2_E_INVALID;
+  if (width == 0 || height == 0) return LCP2_OK;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_HIP(ctx, hipMemcpy2DAsync(dev_dst, dst_pitch, dev_src, src_pitch, width, height, hipMemcpyDeviceToDevice, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LCP2_OK;
+}
 extern "C" int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
   if (!ctx || !host_dst || !dev_src) return LCP2_E_INVALID;
   LCP2_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));

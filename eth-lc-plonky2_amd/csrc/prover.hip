@@ -56,6 +56,17 @@ struct lcp2_circuit {
   bool cap_final = true;
   bool sharded() const { return bc != 0; }
   uint32_t nblocks() const { return bc ? bc : (1u << p.rate_bits); }
+  // row exchange form of a sharded proof (lcp2_commit_wires_rows): the handle holds the witness VALUES of the rows
+  // [row0(), row0() + rows()) only - rank r of `world` holds the r-th block of n / world rows - and runs the permutation
+  // argument and the gate check on them
+  bool rows_mode = false, cs_rows_ready = false;
+  DevBuf cs_rows;   // the constants on this rank's rows, [num_constants][rows()]
+  DevBuf zs_rows;   // exchange buffer of Z / partial products, [world][num_challenges * (1 + npp)][rows()]
+  u64 perm_wrap[2 * QUOTIENT_MAX_CH] = {0};  // per challenge: Z before the block's last row, the last row's quotient (host)
+  uint32_t world() const { return bc ? (1u << p.rate_bits) / bc : 1; }
+  uint32_t rank() const { return bc ? bf / bc : 0; }
+  u64 rows() const { return rows_mode ? (1ull << p.degree_bits) / world() : (1ull << p.degree_bits); }
+  u64 row0() const { return rows_mode ? rows() * rank() : 0; }
 };
 
 namespace lcp2 {
@@ -89,7 +100,7 @@ namespace {
 
 // word offsets inside lcp2_circuit::small (per-proof scalars on the device)
 constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
-                 SMALL_CHECK = 21, SMALL_NONCANON = 22, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
+                 SMALL_CHECK = 21, SMALL_NONCANON = 22, SMALL_PERM_PREFIX = 24, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
 
 inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
 
@@ -515,8 +526,12 @@ namespace {
 
 // PolynomialBatch::from_values on the witness (K1-K4).  d_coeffs (nullable, device): the coefficients of every wire column,
 // already computed (a sharded proof runs the iNTT polynomial-parallel across the ranks and all-gathers the result).
-int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const u64 *d_coeffs, u64 *cap_out) {
+// rows_only: `wires_in` is this rank's row block of the values, [num_wires][n / world] (device), see lcp2_commit_wires_rows.
+int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const u64 *d_coeffs, u64 *cap_out, bool rows_only = false) {
   LCP2_STAGE_PROLOGUE
+  if (rows_only && (!c->sharded() || !d_coeffs || wires_mem != LCP2_MEM_DEVICE || n < c->world()))
+    return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_rows: needs a sharded circuit with at least one row per rank, device buffers");
+  c->rows_mode = rows_only;
   const u64 *d_wires = wires_in;
   if (wires_mem == LCP2_MEM_HOST) {
     LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
@@ -531,7 +546,13 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
   LCP2_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, s));
   if (d_coeffs) {
     LCP2_TRY(commit_coeffs_dev(ctx, d_coeffs, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, true));
-    launch_canon_copy(s, d_wires, nullptr, (u64)W * n, d_flag);  // the values did not pass through an iNTT here: scan them
+    launch_canon_copy(s, d_wires, nullptr, (u64)W * c->rows(), d_flag);  // the values did not pass through an iNTT here: scan them
+    if (rows_only && !c->cs_rows_ready) {  // the gate check reads the constants with the stride of the wires
+      const u64 R = c->rows();
+      LCP2_HIP(ctx, c->cs_rows.ensure((size_t)NC * R * 8));
+      LCP2_HIP(ctx, hipMemcpy2DAsync(c->cs_rows.p, R * 8, c->cs_values.u() + c->row0(), n * 8, R * 8, NC, hipMemcpyDeviceToDevice, s));
+      c->cs_rows_ready = true;
+    }
   } else {
     LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, d_flag));
   }
@@ -541,52 +562,108 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
   return LCP2_OK;
 }
 
-// wires_permutation_partial_products_and_zs + commitment (K5, K1-K4)
-int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap_out) {
+// wires_permutation_partial_products_and_zs + commitment (K5, K1-K4), in three steps so that a sharded proof in the row
+// exchange form can run K5 on its own rows: perm_begin (chunk products and their running product inside the block),
+// perm_finish (Z and the partial products, times the product of the blocks before this one), perm_commit.
+PermArgs perm_args(lcp2_circuit *c, NttHost<DeviceNttBackend> &ntt, u64 *zs_out) {
+  const lcp2_params &p = c->p;
+  const u64 n = 1ull << p.degree_bits, R = c->rows();
+  u64 *d_small = c->small.u();
+  PermArgs a{};
+  a.wires = c->d_wires_cur; a.wires_stride = R;
+  a.sigmas = c->cs_values.u() + (u64)p.num_constants * n + c->row0(); a.sigma_stride = n;
+  a.k_is = c->d_kis.u();
+  a.subgroup = ntt.root_table(p.degree_bits, false);
+  a.betas = d_small + SMALL_BETAS; a.gammas = d_small + SMALL_GAMMAS; a.prefix = nullptr;
+  a.chunk_q = c->chunk_q.u(); a.row_tot = c->row_tot.u(); a.zs_out = zs_out;
+  a.n = R; a.row0 = c->row0();
+  a.num_routed = p.num_routed_wires; a.chunk = p.quotient_degree_factor; a.nchunks = npp_of(p) + 1; a.num_challenges = p.num_challenges;
+  return a;
+}
+// where K5 writes: the value buffer of the commitment, or this rank's slot of the exchange buffer
+u64 *perm_out(lcp2_circuit *c) {
+  const u64 ncz = (u64)c->p.num_challenges * (1 + npp_of(c->p));
+  return c->rows_mode ? c->zs_rows.u() + (u64)c->rank() * ncz * c->rows() : c->zs_vals.u();
+}
+
+int perm_begin(lcp2_circuit *c, const u64 *betas, const u64 *gammas) {
   LCP2_STAGE_PROLOGUE
   if (c->stage < lcp2_circuit::ST_WIRES) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
-  const u64 *d_wires = c->d_wires_cur;
+  const u64 R = c->rows();
   u64 *d_small = c->small.u();
-  u64 *d_betas = d_small + SMALL_BETAS, *d_gammas = d_small + SMALL_GAMMAS;
   u64 bc[4] = {0}, gc[4] = {0};
   for (u32 k = 0; k < CH; k++) { bc[k] = gl_canon(betas[k]); gc[k] = gl_canon(gammas[k]); }
-  LCP2_HIP(ctx, hipMemcpyAsync(d_betas, bc, CH * 8, hipMemcpyHostToDevice, s));
-  LCP2_HIP(ctx, hipMemcpyAsync(d_gammas, gc, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_small + SMALL_BETAS, bc, CH * 8, hipMemcpyHostToDevice, s));
+  LCP2_HIP(ctx, hipMemcpyAsync(d_small + SMALL_GAMMAS, gc, CH * 8, hipMemcpyHostToDevice, s));
   u64 noncanonical = 0;
   LCP2_HIP(ctx, hipMemcpyAsync(&noncanonical, d_small + SMALL_NONCANON, 8, hipMemcpyDeviceToHost, s));
   LCP2_HIP(ctx, hipStreamSynchronize(s));
   if (noncanonical) {  // rare: a witness with values in [p, 2^64): continue from a canonical copy (stage_wires)
-    LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
-    launch_canon_copy(s, d_wires, c->wires_vals.u(), (u64)W * n, nullptr);  // (a host witness is already the library's copy: in place)
-    d_wires = c->d_wires_cur = c->wires_vals.u();
+    LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * R * 8));
+    launch_canon_copy(s, c->d_wires_cur, c->wires_vals.u(), (u64)W * R, nullptr);  // (a host witness is already the library's copy: in place)
+    c->d_wires_cur = c->wires_vals.u();
   }
-  // ---- K5: Z and partial products on H
+  if (c->rows_mode) LCP2_HIP(ctx, c->zs_rows.ensure((size_t)CH * (1 + npp) * n * 8));
+  // ---- K5: the quotient chunks of every row and Z inside the block (exclusive prefix product of the row totals)
+  u64 *zs_out = perm_out(c);
+  PermArgs a = perm_args(c, ntt, zs_out);
+  if (be.status) return be.status;
   {
-    PermArgs a{};
-    a.wires = d_wires; a.sigmas = c->cs_values.u() + (u64)NC * n; a.k_is = c->d_kis.u();
-    a.subgroup = ntt.root_table(p.degree_bits, false);
-    a.betas = d_betas; a.gammas = d_gammas; a.chunk_q = c->chunk_q.u(); a.row_tot = c->row_tot.u(); a.zs_out = c->zs_vals.u();
-    a.n = n; a.num_routed = NR; a.chunk = Q; a.nchunks = nchunks; a.num_challenges = CH;
-    if (be.status) return be.status;
-    ProfScope ps(ctx, LCP2_K_PERM_Z, (double)n * 8.0 * (2.0 * NR + CH * (1.0 + npp)));
+    ProfScope ps(ctx, LCP2_K_PERM_Z, (double)R * 8.0 * (2.0 * NR + CH * (1.0 + npp)));
     launch_perm_chunks(s, a);
-    launch_scan(s, true, c->row_tot.u(), c->zs_vals.u(), c->scan_tmp.u(), n, false, CH, n);
-    launch_perm_finalize(s, a);
+    launch_scan(s, true, c->row_tot.u(), zs_out, c->scan_tmp.u(), R, false, CH, R);
   }
   LCP2_HIP(ctx, hipGetLastError());
+  for (u32 k = 0; k < CH; k++) {  // lands with the caller's next synchronisation of the stream
+    LCP2_HIP(ctx, hipMemcpyAsync(&c->perm_wrap[2 * k], zs_out + (u64)k * R + (R - 1), 8, hipMemcpyDeviceToHost, s));
+    LCP2_HIP(ctx, hipMemcpyAsync(&c->perm_wrap[2 * k + 1], c->row_tot.u() + (u64)k * R + (R - 1), 8, hipMemcpyDeviceToHost, s));
+  }
+  return LCP2_OK;
+}
+
+// prefix (nullable, host, [CH]): the product of the row blocks before this one
+int perm_finish(lcp2_circuit *c, const u64 *prefix) {
+  LCP2_STAGE_PROLOGUE
+  PermArgs a = perm_args(c, ntt, perm_out(c));
+  if (be.status) return be.status;
+  if (prefix) {
+    LCP2_HIP(ctx, hipMemcpyAsync(c->small.u() + SMALL_PERM_PREFIX, prefix, CH * 8, hipMemcpyHostToDevice, s));
+    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `prefix` is the caller's
+    a.prefix = c->small.u() + SMALL_PERM_PREFIX;
+  }
+  ProfScope ps(ctx, LCP2_K_PERM_Z, (double)c->rows() * 8.0 * CH * (1.0 + 2.0 * npp));
+  launch_perm_finalize(s, a);
+  LCP2_HIP(ctx, hipGetLastError());
+  return LCP2_OK;
+}
+
+int perm_commit(lcp2_circuit *c, u64 *cap_out) {
+  LCP2_STAGE_PROLOGUE
+  const u32 ncz = CH * (1 + npp);
+  if (c->rows_mode) {  // the exchange buffer holds every rank's rows, [rank][column][rows]: back to whole columns
+    const u64 R = c->rows();
+    for (u32 r = 0; r < c->world(); r++)
+      LCP2_HIP(ctx, hipMemcpy2DAsync(c->zs_vals.u() + (u64)r * R, n * 8, c->zs_rows.u() + (u64)r * ncz * R, R * 8, R * 8, ncz, hipMemcpyDeviceToDevice, s));
+  }
+  LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), ncz, p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
+  LCP2_TRY(download_cap(c, c->zs, cap_out));  // synchronises the stream
+  c->stage = lcp2_circuit::ST_ZS;
+  return LCP2_OK;
+}
+
+int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap_out) {
+  if (c->rows_mode) return c->ctx->fail(LCP2_E_INVALID, "row exchange form: lcp2_perm_zs_rows_begin / _finish / lcp2_perm_zs_commit");
+  LCP2_TRY(perm_begin(c, betas, gammas));
+  LCP2_TRY(perm_finish(c, nullptr));
+  LCP2_TRY(perm_commit(c, cap_out));  // synchronises the stream: perm_wrap has landed
   // Copy constraints: Z must come back to 1 after the last row, Z(g^(n-1)) * (row n-1's quotient) = 1, which holds for
   // every beta, gamma exactly when the wire values are constant on the cycles of sigma (up to the soundness error of the
   // argument itself).  plonky2 reports a broken copy constraint as an Err of prove(); so does this (LCP2_E_UNSAT).
-  u64 wrap[2 * QUOTIENT_MAX_CH];
-  for (u32 k = 0; k < CH; k++) {
-    LCP2_HIP(ctx, hipMemcpyAsync(&wrap[2 * k], c->zs_vals.u() + (u64)k * n + (n - 1), 8, hipMemcpyDeviceToHost, s));
-    LCP2_HIP(ctx, hipMemcpyAsync(&wrap[2 * k + 1], c->row_tot.u() + (u64)k * n + (n - 1), 8, hipMemcpyDeviceToHost, s));
-  }
-  LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), CH * (1 + npp), p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
-  LCP2_TRY(download_cap(c, c->zs, cap_out));  // synchronises the stream: `wrap` has landed
-  for (u32 k = 0; k < CH; k++)
-    if (gl_mul(wrap[2 * k], wrap[2 * k + 1]) != 1) return ctx->fail(LCP2_E_UNSAT, "the witness violates a copy constraint (the permutation product does not return to 1)");
-  c->stage = lcp2_circuit::ST_ZS;
+  for (u32 k = 0; k < c->p.num_challenges; k++)
+    if (gl_mul(c->perm_wrap[2 * k], c->perm_wrap[2 * k + 1]) != 1) {
+      c->stage = lcp2_circuit::ST_WIRES;
+      return c->ctx->fail(LCP2_E_UNSAT, "the witness violates a copy constraint (the permutation product does not return to 1)");
+    }
   return LCP2_OK;
 }
 
@@ -636,14 +713,14 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     ProfScope ps(ctx, LCP2_K_QUOTIENT, (double)a.count * 8.0 * (W + ncs + CH * (1.0 + npp) + 2.0 + CH) + 8.0 * n * (W + NC));
     // the gate constraints on the n rows of H first (1/8 of the work below): a witness that violates one is the Err of prove()
     QuotientArgs h = a;
-    h.wires = c->d_wires_cur; h.consts = c->cs_values.u(); h.leaf0 = 0; h.count = n; h.stride = n;
+    h.wires = c->d_wires_cur; h.consts = c->rows_mode ? c->cs_rows.u() : c->cs_values.u(); h.leaf0 = 0; h.count = c->rows(); h.stride = c->rows();
     launch_gate_check(s, h, c->dev_gates, (unsigned long long *)(d_small + SMALL_CHECK));
     launch_quotient(s, a, c->dev_gates);
   }
   LCP2_HIP(ctx, hipGetLastError());
   u64 bad_row = ~0ull;
   LCP2_TRY(download(ctx, &bad_row, d_small + SMALL_CHECK, 8));  // synchronises the stream
-  if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1));
+  if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1 + c->row0()));
   c->stage = lcp2_circuit::ST_QVALS;
   return LCP2_OK;
 }
@@ -1017,6 +1094,49 @@ extern "C" int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, 
   if (!c || !wires || !coeffs || !cap) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
   return stage_wires(c, (const u64 *)wires, LCP2_MEM_DEVICE, (const u64 *)coeffs, (u64 *)cap);
+}
+extern "C" int lcp2_commit_wires_rows(lcp2_circuit *c, const uint64_t *wire_rows, const uint64_t *coeffs, uint64_t *cap) {
+  if (!c || !wire_rows || !coeffs || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  return stage_wires(c, (const u64 *)wire_rows, LCP2_MEM_DEVICE, (const u64 *)coeffs, (u64 *)cap, true);
+}
+extern "C" int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *block_products) {
+  if (!c || !betas || !gammas || !block_products) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (!c->rows_mode) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_begin: the wires were not committed with lcp2_commit_wires_rows");
+  LCP2_TRY(perm_begin(c, (const u64 *)betas, (const u64 *)gammas));
+  if (hipStreamSynchronize(c->ctx->stream) != hipSuccess) return c->ctx->fail(LCP2_E_HIP, "lcp2_perm_zs_rows_begin: stream synchronisation failed");
+  const u32 CH = c->p.num_challenges;
+  memset(block_products, 0, (size_t)c->world() * CH * 8);
+  for (u32 k = 0; k < CH; k++) block_products[(size_t)c->rank() * CH + k] = gl_mul(c->perm_wrap[2 * k], c->perm_wrap[2 * k + 1]);
+  return LCP2_OK;
+}
+extern "C" int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_products, uint64_t **device_ptr, size_t *words) {
+  if (!c || !block_products || !device_ptr || !words) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_finish: no permutation argument in flight");
+  const u32 CH = c->p.num_challenges;
+  u64 prefix[QUOTIENT_MAX_CH];
+  for (u32 k = 0; k < CH; k++) {
+    u64 all = 1;
+    prefix[k] = 1;
+    for (u32 r = 0; r < c->world(); r++) {
+      if (r == c->rank()) prefix[k] = all;
+      all = gl_mul(all, gl_canon(block_products[(size_t)r * CH + k]));
+    }
+    // every rank sees the same products: all of them report the broken copy constraint (stage_perm_zs has the argument)
+    if (all != 1) return c->ctx->fail(LCP2_E_UNSAT, "the witness violates a copy constraint (the permutation product does not return to 1)");
+  }
+  LCP2_TRY(perm_finish(c, prefix));
+  *device_ptr = (uint64_t *)c->zs_rows.p;
+  *words = (size_t)CH * (1 + npp_of(c->p)) << c->p.degree_bits;
+  return LCP2_OK;
+}
+extern "C" int lcp2_perm_zs_commit(lcp2_circuit *c, uint64_t *cap) {
+  if (!c || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_commit: no permutation argument in flight");
+  return perm_commit(c, (u64 *)cap);
 }
 extern "C" int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap) {
   if (!c || !betas || !gammas || !cap) return LCP2_E_INVALID;

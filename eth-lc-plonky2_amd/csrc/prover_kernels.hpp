@@ -27,15 +27,18 @@ struct GateDev {  // = lcp2_gate
 };
 
 struct PermArgs {
-  const u64 *wires;    // witness values on H, [num_wires][n]
-  const u64 *sigmas;   // sigma values on H, [num_routed][n]
+  const u64 *wires;    // witness values on the rows [row0, row0 + n) of H, [num_wires][wires_stride]
+  const u64 *sigmas;   // sigma values on the same rows (the pointer is to row0), [num_routed][sigma_stride]
   const u64 *k_is;     // [num_routed]
   TwoLevelTable subgroup;  // w_n^row
   const u64 *betas, *gammas;  // device, [num_challenges]
+  const u64 *prefix;   // nullable, [num_challenges]: k_perm_finalize multiplies Z and the partial products by it (a row block of a
+                       // sharded proof: the product of the blocks before it)
   u64 *chunk_q;        // scratch [num_challenges][nchunks][n]
   u64 *row_tot;        // scratch [num_challenges][n]
   u64 *zs_out;         // [num_challenges * (1 + npp)][n]: Z_0.., then partial products per challenge
-  u64 n;
+  u64 n, row0;         // rows of this launch (all of H: row0 = 0) and the global index of the first
+  u64 wires_stride, sigma_stride;
   u32 num_routed, chunk, nchunks, num_challenges;
 };
 

@@ -113,12 +113,19 @@ class ShardedProver:
                        the 140 KB proof array (uint64 wrap-around; RCCL has no bitwise reductions)
         openings, FRI  a rank evaluates its share of the columns at zeta and commits its leaf blocks of FRI layer 0 (folding is in
                        coefficient form: no FRI values cross the ranks); shares of the 4 KB of openings and of the layer-0 cap
+        witness, row exchange form (prove_steps(..., sharded_columns=True, row_exchange=True)): the values are needed only
+                       by the permutation argument and the gate check, both row-wise, so instead of all-gathering them each rank
+                       receives its block of n / world rows of every column by an all-to-all (1 / world of the bytes), runs K5 and
+                       the check on those rows, and the Z / partial-product rows are all-gathered (20 columns instead of 135):
+                       8.4 -> 5.5 GB received per rank at n = 2^22 over 8 ranks
         quotient       each challenge plane of the value buffer is completed by an in-place all-gather of the ranks' contiguous
                        leaf blocks (537 MB in total at n = 2^22, each byte crosses the fabric once)
     `comm` supplies the collectives, so that the same orchestration runs over torch.distributed (TorchComm: "nccl" = RCCL on
     the node, "gloo" in the CPU tests) and, in the single-GPU tests, over ranks stepped in lockstep inside one process:
         comm.sum_host(numpy uint64 array) -> numpy uint64 array
-        comm.all_gather_device(device pointer, total words, words per rank)    in place: rank r's part sits at r * words per rank"""
+        comm.all_gather_device(device pointer, total words, words per rank)    in place: rank r's part sits at r * words per rank
+        comm.all_to_all_device(send pointer, receive pointer, words per pair)  part d of the send buffer goes to rank d, part s of
+                                                                               the receive buffer comes from rank s"""
 
     def __init__(self, ctx, circ, rank, world, comm, constants_sigmas_ptr=None, mem=0):
         from . import binding as b
@@ -127,6 +134,7 @@ class ShardedProver:
         self.data = b.CircuitData.build_sharded(ctx, circ, first, count, constants_sigmas_ptr, mem)
         self.cap_share = self.data.digest()[1]
         self._vals = self._coeffs = None
+        self._row_bufs = None
 
     def finish_build(self):
         self.data.set_constants_cap(self.comm.sum_host(self.cap_share))
@@ -140,13 +148,26 @@ class ShardedProver:
         n = 1 << self.circ.params.degree_bits
         words = self.world * most * n
         if self._vals is None:
-            self._vals, self._coeffs = self.ctx.buffer_alloc(words), self.ctx.buffer_alloc(words)
+            self._vals = self.ctx.buffer_alloc(words)
+        if self._coeffs is None:
+            self._coeffs = self.ctx.buffer_alloc(words)
         return self._vals, self._coeffs
 
+    def _close_gaps(self, buf, shards, most, run):
+        """a padded per-rank layout [rank][most][run] -> [column][run] when a shard in the middle is short: column by column, in
+        increasing order (source and destination never overlap)"""
+        if all(e - s == most for s, e in shards[:-1]):
+            return
+        for r, (s0, e0) in enumerate(shards):
+            for col in range(e0 - s0):
+                if r * most != s0:
+                    self.ctx.buffer_copy(buf + 8 * (s0 + col) * run, buf + 8 * (r * most + col) * run, run)
+
     # the proof as a generator of exchange points, so that a test can interleave several ranks in one process
-    def prove_steps(self, wires, public_inputs, mem=0, sharded_columns=False):
+    def prove_steps(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False):
         """wires: the whole witness [num_wires][n] (numpy, or a device pointer with mem=MEM_DEVICE); with sharded_columns=True
-        only this rank's columns [column_shard()][n]."""
+        only this rank's columns [column_shard()][n].  row_exchange (with sharded_columns): the values cross the ranks as row
+        blocks (all-to-all) instead of whole columns (all-gather), see the class comment."""
         b, d, p, ctx = self.b, self.data, self.circ.params, self.ctx
         capw = 4 << p.cap_height
         n = 1 << p.degree_bits
@@ -156,39 +177,76 @@ class ShardedProver:
         ch.observe(self.digest)
         pi_hash = b.hash_no_pad(pis)
         ch.observe(pi_hash)
+        if row_exchange and not (sharded_columns and n >= self.world):
+            raise ValueError("row_exchange needs the column-sharded arrival and at least one row per rank")
         if sharded_columns:
             shards = column_shards(p.num_wires, self.world)
             most = max(e - s for s, e in shards)
             first, end = shards[self.rank]
-            vals, coeffs = self._witness_buffers(most)
             mine = self.rank * most * n  # word offset of this rank's slot
-            if mem == b.MEM_HOST:
-                ctx.buffer_write(vals + 8 * mine, np.ascontiguousarray(wires, dtype=np.uint64).reshape(end - first, n))
+            if row_exchange:
+                # own columns [most][n]; their row blocks for every rank [world][most][rows]; the blocks received [world][most][rows]
+                if self._row_bufs is None:
+                    self._row_bufs = [ctx.buffer_alloc(most * n) for _ in range(3)]
+                if self._coeffs is None:
+                    self._coeffs = ctx.buffer_alloc(self.world * most * n)
+                own, send, recv = self._row_bufs
+                coeffs = self._coeffs
             else:
-                ctx.buffer_copy(vals + 8 * mine, wires, (end - first) * n)
-            yield ("all_gather_device", vals, self.world * most * n, most * n)
+                vals, coeffs = self._witness_buffers(most)
+                own = vals + 8 * mine
+            if mem == b.MEM_HOST:
+                ctx.buffer_write(own, np.ascontiguousarray(wires, dtype=np.uint64).reshape(end - first, n))
+            else:
+                ctx.buffer_copy(own, wires, (end - first) * n)
+            if not row_exchange:
+                yield ("all_gather_device", vals, self.world * most * n, most * n)
             # polynomial-parallel iNTT: own columns only, then the coefficient all-gather
-            ctx.buffer_copy(coeffs + 8 * mine, vals + 8 * mine, (end - first) * n)
+            ctx.buffer_copy(coeffs + 8 * mine, own, (end - first) * n)
             if end > first:
                 ctx._check(ctx.lib.lcp2_ntt_batch(ctx.handle, ctypes.c_void_p(coeffs + 8 * mine), end - first, p.degree_bits, 1, 1, b.MEM_DEVICE))
             yield ("all_gather_device", coeffs, self.world * most * n, most * n)
-            if any(e - s != most for s, e in shards[:-1]):  # a short shard in the middle: close the gaps (both buffers alike)
-                for buf in (vals, coeffs):               # column by column, in increasing order: source and destination never overlap
-                    for r, (s0, e0) in enumerate(shards):
-                        for col in range(e0 - s0):
-                            if r * most != s0:
-                                ctx.buffer_copy(buf + 8 * (s0 + col) * n, buf + 8 * (r * most + col) * n, n)
-            share = d.commit_wires_coeffs(vals, coeffs)
+            self._close_gaps(coeffs, shards, most, n)
+            if row_exchange:
+                rows = n // self.world
+                for dst in range(self.world):  # rank dst's rows of this rank's columns
+                    ctx.buffer_copy_2d(send + 8 * dst * most * rows, rows, own + 8 * dst * rows, n, rows, end - first)
+                yield ("all_to_all_device", send, recv, most * rows)
+                self._close_gaps(recv, shards, most, rows)
+                share = d.commit_wires_rows(recv, coeffs)
+            else:
+                self._close_gaps(vals, shards, most, n)
+                share = d.commit_wires_coeffs(vals, coeffs)
         else:
             share = d.commit_wires(wires, mem)
         proof[0:capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[0:capw])
         betas, gammas = ch.get(p.num_challenges), ch.get(p.num_challenges)
-        share = d.perm_zs(betas, gammas)
+        if row_exchange:
+            products = yield ("sum_host", d.perm_zs_rows_begin(betas, gammas, self.world))
+            zptr, zwords = d.perm_zs_rows_finish(products)  # raises on every rank alike if the product does not return to 1
+            yield ("all_gather_device", zptr, zwords, zwords // self.world)
+            share = d.perm_zs_commit()
+        else:
+            share = d.perm_zs(betas, gammas)
         proof[capw:2 * capw] = (yield ("sum_host", share)).ravel()
         ch.observe(proof[capw:2 * capw])
         alphas = ch.get(p.num_challenges)
-        d.quotient_values(alphas, pi_hash)
+        if row_exchange:  # each rank checks the gates on its own rows: the verdict is exchanged before the next collective
+            failure = None
+            try:
+                d.quotient_values(alphas, pi_hash)
+            except b.Lcp2Error as e:
+                if e.status != b.E_UNSAT:
+                    raise
+                failure = e
+            verdicts = yield ("sum_host", np.array([failure is not None], dtype=np.uint64))
+            if failure is not None:
+                raise failure
+            if int(verdicts[0]):
+                raise b.Lcp2Error(b.E_UNSAT, "another rank reports a violated gate constraint")
+        else:
+            d.quotient_values(alphas, pi_hash)
         qptr, qwords = d.quotient_buffer()
         plane = qwords // p.num_challenges  # 8n words per challenge; this rank's blocks are one contiguous run of it
         for c in range(p.num_challenges):
@@ -212,14 +270,17 @@ class ShardedProver:
         self.proof = proof
         return
 
-    def prove(self, wires, public_inputs, mem=0, sharded_columns=False):
-        steps = self.prove_steps(wires, public_inputs, mem, sharded_columns)
+    def prove(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False):
+        steps = self.prove_steps(wires, public_inputs, mem, sharded_columns, row_exchange)
         reply = None
         try:
             while True:
                 req = steps.send(reply)
                 if req[0] == "sum_host":
                     reply = self.comm.sum_host(req[1])
+                elif req[0] == "all_to_all_device":
+                    self.comm.all_to_all_device(req[1], req[2], req[3])
+                    reply = None
                 else:
                     self.comm.all_gather_device(req[1], req[2], req[3])
                     reply = None
@@ -227,10 +288,10 @@ class ShardedProver:
             return self.proof
 
     def close(self):
-        for buf in (self._vals, self._coeffs):
+        for buf in [self._vals, self._coeffs] + list(self._row_bufs or []):
             if buf:
                 self.ctx.buffer_free(buf)
-        self._vals = self._coeffs = None
+        self._vals = self._coeffs = self._row_bufs = None
         self.data.close()
 
 
@@ -288,6 +349,17 @@ class TorchComm:
         self.all_gather_tensor(out, self.dist.get_rank())
         torch.cuda.synchronize(self.device)
         self.bytes_gathered += 8 * words_per_rank * (world - 1)
+
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        """part d of the send buffer goes to rank d; part s of the receive buffer comes from rank s (both library buffers)"""
+        import torch
+        world = self.dist.get_world_size()
+        self.ctx.sync()
+        send = torch.as_tensor(_DevicePtr(send_ptr, world * words_per_pair), device=self.device)
+        recv = torch.as_tensor(_DevicePtr(recv_ptr, world * words_per_pair), device=self.device)
+        self.dist.all_to_all_single(recv, send)
+        torch.cuda.synchronize(self.device)
+        self.bytes_gathered += 8 * words_per_pair * (world - 1)
 
     def self_check(self, words_per_rank=1 << 16):
         """Known-answer all-gather on a library buffer.  Returns "in-place" or "staged" (the form that will be used), raises if

@@ -173,6 +173,8 @@ int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes);
 int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 int lcp2_buffer_write(lcp2_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_src, size_t bytes);   /* device to device, on the context's stream */
+/* `height` runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart (device to device): row blocks out of / into columns */
+int lcp2_buffer_copy_2d(lcp2_ctx *ctx, void *dev_dst, size_t dst_pitch, const void *dev_src, size_t src_pitch, size_t width, size_t height);
 
 /* ------------------------------------------------------------------ polynomial commitments
  * PolynomialBatch::from_values / from_coeffs (plonky2 fri/oracle.rs): ifft,
@@ -379,6 +381,24 @@ int lcp2_circuit_set_constants_cap(lcp2_circuit *c, const uint64_t *cap);
  * and all-gathers the coefficients over RCCL (the "column transpose" of the commitment); the values are still needed
  * for the permutation argument and the LCP2_E_UNSAT check.  The coefficients are copied into the circuit's oracle. */
 int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, const uint64_t *coeffs, uint64_t *cap);
+/* Row exchange form of the same proof: the witness VALUES are needed only by the permutation argument (K5) and the gate check,
+ * both row-wise, so rank r of `world` = 2^rate_bits / block_count takes just the rows [r * n / world, (r + 1) * n / world) of
+ * every column - an all-to-all of row blocks out of the column shards (1 / world of the witness per rank) instead of the
+ * all-gather of all values - and the ranks exchange what K5 makes of them:
+ *   lcp2_commit_wires_rows      wire_rows: device, [num_wires][n / world]; coeffs as in lcp2_commit_wires_coeffs -> cap share
+ *   lcp2_perm_zs_rows_begin     the quotient chunks of the rank's rows and their running product inside the block;
+ *                               block_products[world][num_challenges]: this rank's entry, zeros elsewhere (a share to be summed)
+ *   lcp2_perm_zs_rows_finish    block_products: the sum of the shares.  Z and the partial products of the rank's rows, times the
+ *                               product of the blocks before it, go into the rank's slot of the exchange buffer
+ *                               [world][num_challenges * (1 + npp)][n / world] (*device_ptr, *words in total): an in-place
+ *                               all-gather completes it.  LCP2_E_UNSAT (on every rank alike) if the product over all blocks is not 1.
+ *   lcp2_perm_zs_commit         iNTT / LDE / Merkle tree of the completed buffer -> cap share
+ * lcp2_quotient_values then checks the gates on the rank's rows only: a caller must exchange the status (a rank that got
+ * LCP2_E_UNSAT stops, and so must the others) before the next collective. */
+int lcp2_commit_wires_rows(lcp2_circuit *c, const uint64_t *wire_rows, const uint64_t *coeffs, uint64_t *cap);
+int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *block_products);
+int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_products, uint64_t **device_ptr, size_t *words);
+int lcp2_perm_zs_commit(lcp2_circuit *c, uint64_t *cap);
 int lcp2_quotient_values(lcp2_circuit *c, const uint64_t *alphas, const uint64_t public_inputs_hash[4]);
 int lcp2_quotient_buffer(lcp2_circuit *c, uint64_t **device_ptr, size_t *words);
 int lcp2_quotient_commit(lcp2_circuit *c, uint64_t *cap);

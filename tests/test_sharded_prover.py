@@ -32,8 +32,16 @@ class LockstepComm:
             for r, part in enumerate(parts):
                 self.ctx.buffer_write(ptr + 8 * r * wpr, part)
 
+    def all_to_all_device_all(self, reqs):
+        """reqs[r] = (send pointer, receive pointer, words per pair) of rank r: part d of rank s's send buffer becomes part s of
+        rank d's receive buffer"""
+        world = len(reqs)
+        sends = [self.ctx.buffer_read(send, world * wpp).reshape(world, wpp) for send, recv, wpp in reqs]
+        for d, (send, recv, wpp) in enumerate(reqs):
+            self.ctx.buffer_write(recv, np.ascontiguousarray(np.stack([sends[src][d] for src in range(world)])).ravel())
 
-def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False):
+
+def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False, row_exchange=False):
     comm = LockstepComm(ctx)
     ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
     cap = comm.sum_host_all([r.cap_share for r in ranks])
@@ -41,7 +49,8 @@ def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False):
         r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
         r.finish_build()
     if sharded_columns:  # every rank brings only its column shard of the witness
-        gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True) for r in ranks]
+        gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True, row_exchange=row_exchange)
+                for r in ranks]
     else:
         gens = [r.prove_steps(wires, pis) for r in ranks]
     replies = [None] * world
@@ -58,6 +67,9 @@ def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False):
         if reqs[0][0] == "sum_host":
             merged = comm.sum_host_all([q[1] for q in reqs])
             replies = [merged.copy() for _ in range(world)]
+        elif reqs[0][0] == "all_to_all_device":
+            comm.all_to_all_device_all([(q[1], q[2], q[3]) for q in reqs])
+            replies = [None] * world
         else:
             comm.all_gather_device_all([(q[1], q[2], q[3]) for q in reqs])
             replies = [None] * world
@@ -103,6 +115,111 @@ def test_sharded_columns_with_a_short_middle_shard(gpu_ctx):
     assert (ranks[3].proof == want).all()
     for r in ranks:
         r.close()
+    single.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 6, 135), (8, 5, 135), (8, 4, 135), (8, 7, 140)])
+def test_row_exchange_proof_equals_single_gpu(gpu_ctx, world, degree_bits, num_wires):
+    """the row exchange form (include/lcp2.h): the witness values cross the ranks as row blocks, K5 and the gate check run on a
+    rank's own rows, the Z / partial-product rows are all-gathered.  (8, 4): two rows per rank; (8, 7, 140): gaps in the padded
+    layouts of the all-gather and of the all-to-all"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(degree_bits, 4)
+    params.num_wires = num_wires
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1200 + world + degree_bits)
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, world, True, True)
+    for r in ranks:
+        bad = np.nonzero(r.proof != want)[0]
+        assert bad.size == 0, f"rank {r.rank}/{world}: {bad.size} proof words differ, first at {bad[0]}"
+    # the same handles take the whole-column form again afterwards (the row mode is per proof)
+    again = _rerun(m, gpu_ctx, ranks, wires, pis, world)
+    assert (again == want).all()
+    for r in ranks:
+        r.close()
+    single.close()
+
+
+def _rerun(m, ctx, ranks, wires, pis, world):
+    comm = LockstepComm(ctx)
+    gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True) for r in ranks]
+    replies = [None] * world
+    while True:
+        reqs = []
+        for g, rep in zip(gens, replies):
+            try:
+                reqs.append(g.send(rep))
+            except StopIteration:
+                reqs.append(None)
+        if all(q is None for q in reqs):
+            return ranks[-1].proof
+        if reqs[0][0] == "sum_host":
+            merged = comm.sum_host_all([q[1] for q in reqs])
+            replies = [merged.copy() for _ in range(world)]
+        else:
+            comm.all_gather_device_all([(q[1], q[2], q[3]) for q in reqs])
+            replies = [None] * world
+
+
+@pytest.mark.gpu
+def test_row_exchange_reports_an_unsatisfied_witness_on_every_rank(gpu_ctx):
+    """a violated gate constraint is found by the rank that holds the row and reaches the others through the verdict exchange;
+    a broken copy constraint shows in the product of the block products, which every rank computes"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(8, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=77)
+    single = m.CircuitData.build(gpu_ctx, circ)
+    for what in ("gate", "copy"):
+        bad = wires.copy()
+        row = 5 * 32 + 5  # a BaseSumGate row in rank 5's block; its limbs are in no copy class
+        if what == "gate":
+            bad[1, row] ^= np.uint64(1)  # still a bit, but the limbs no longer sum to wire 0
+            with pytest.raises(m.Lcp2Error, match=f"gate constraint on row {row}"):
+                single.prove(bad, pis)
+        else:
+            first = int(np.nonzero(circ.constants_sigmas[0] == circ.gateset.index("ArithmeticGate"))[0][0])
+            bad[1, first] = np.uint64(12345)  # the first arithmetic row's copy of public input 0 (the permutation argument runs first)
+            with pytest.raises(m.Lcp2Error, match="copy constraint"):
+                single.prove(bad, pis)
+        comm = LockstepComm(gpu_ctx)
+        ranks = [m.parallel.ShardedProver(gpu_ctx, circ, r, 8, None) for r in range(8)]
+        cap = comm.sum_host_all([r.cap_share for r in ranks])
+        for r in ranks:
+            r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
+            r.finish_build()
+        gens = [r.prove_steps(np.ascontiguousarray(bad[slice(*r.column_shard())]), pis, sharded_columns=True, row_exchange=True) for r in ranks]
+        replies, raised = [None] * 8, {}
+        for _ in range(40):
+            reqs = []
+            for k, (g, rep) in enumerate(zip(gens, replies)):
+                if k in raised:
+                    reqs.append(None)
+                    continue
+                try:
+                    reqs.append(g.send(rep))
+                except m.Lcp2Error as e:
+                    raised[k] = e
+                    reqs.append(None)
+            live = [q for q in reqs if q is not None]
+            if not live:
+                break
+            assert len(live) == 8, f"{what}: only some ranks stopped: {sorted(raised)}"   # all or none at every exchange point
+            if live[0][0] == "sum_host":
+                merged = comm.sum_host_all([q[1] for q in reqs])
+                replies = [merged.copy() for _ in range(8)]
+            elif live[0][0] == "all_to_all_device":
+                comm.all_to_all_device_all([(q[1], q[2], q[3]) for q in reqs]); replies = [None] * 8
+            else:
+                comm.all_gather_device_all([(q[1], q[2], q[3]) for q in reqs]); replies = [None] * 8
+        assert sorted(raised) == list(range(8)) and all(e.status == m.binding.E_UNSAT for e in raised.values())
+        if what == "gate":
+            assert f"row {row}" in str(raised[5]) and all("another rank" in str(raised[k]) for k in range(8) if k != 5)
+        else:
+            assert all("copy constraint" in str(e) for e in raised.values())
+        for r in ranks:
+            r.close()
     single.close()
 
 
@@ -165,7 +282,7 @@ def test_host_transcript_helpers_match_oracle(oracle):
     assert list(ch.get(9)) == get(9)
 
 
-_GLOO_WORKER = r"""
+_GLOO_PRELUDE = r"""
 import os, sys
 import numpy as np
 import torch.distributed as dist
@@ -174,6 +291,24 @@ import eth_lc_plonky2_amd as m
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 rank = dist.get_rank()
 comm = m.parallel.TorchComm(dist)
+class FakeCtx:  # "device" buffers are numpy arrays, addressed by their data pointer
+    def __init__(self): self.bufs = {}
+    def buffer_alloc(self, words):
+        a = np.zeros(words, dtype=np.uint64); self.bufs[a.ctypes.data] = a; return a.ctypes.data
+    def buffer_free(self, ptr): del self.bufs[ptr]
+    def _at(self, ptr, words):
+        for base, a in self.bufs.items():
+            if base <= ptr < base + 8 * a.size: return a[(ptr - base) // 8:(ptr - base) // 8 + words]
+        raise KeyError(ptr)
+    def buffer_write(self, ptr, arr): self._at(ptr, arr.size)[:] = np.asarray(arr).ravel()
+    def buffer_read(self, ptr, words): return self._at(ptr, words).copy()
+    def buffer_copy(self, dst, src, words): self._at(dst, words)[:] = self._at(src, words).copy()
+    def buffer_copy_2d(self, dst, dst_pitch, src, src_pitch, width, height):
+        for h in range(height): self._at(dst + 8 * h * dst_pitch, width)[:] = self._at(src + 8 * h * src_pitch, width).copy()
+    def sync(self): pass
+"""
+
+_GLOO_WORKER = _GLOO_PRELUDE + r"""
 # cap shares: rank r owns entries [8r, 8r + 8) of a 16-entry cap
 share = np.zeros((16, 4), dtype=np.uint64)
 share[8 * rank:8 * rank + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) + np.uint64(1000 * (rank + 1)) + (np.uint64(1) << np.uint64(63))
@@ -254,18 +389,6 @@ assert (body[20:30] == 555).all() and (body[30:40] == 556).all() and body[1] == 
 # TorchComm.self_check (what bench.py runs before the sharded proof): a known-answer all-gather on a library buffer; the in-place
 # form is kept when it works, the staged form is chosen - by every rank alike - when the in-place form returns wrong data or the
 # framework refuses it, and the check raises when neither form works
-class FakeCtx:  # "device" buffers are numpy arrays, addressed by their data pointer
-    def __init__(self): self.bufs = {}
-    def buffer_alloc(self, words):
-        a = np.zeros(words, dtype=np.uint64); self.bufs[a.ctypes.data] = a; return a.ctypes.data
-    def buffer_free(self, ptr): del self.bufs[ptr]
-    def _at(self, ptr, words):
-        for base, a in self.bufs.items():
-            if base <= ptr < base + 8 * a.size: return a[(ptr - base) // 8:(ptr - base) // 8 + words]
-        raise KeyError(ptr)
-    def buffer_write(self, ptr, arr): self._at(ptr, arr.size)[:] = arr
-    def buffer_read(self, ptr, words): return self._at(ptr, words).copy()
-    def sync(self): pass
 class CheckComm(m.parallel.TorchComm):
     broken, refuse = False, False
     def all_gather_device(self, ptr, total_words, words_per_rank):
@@ -307,3 +430,110 @@ def test_torch_comm_sum_allreduce_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+# The row exchange form over real gloo collectives: 5 columns of 8 rows over 2 ranks (column shards 3 + 2, row blocks of 4).  The
+# stand-in for the per-rank compute checks what arrives: all coefficients, exactly its own rows of every column, the complete
+# table of block products and the complete Z / partial-product buffer; the gate-check verdict is exchanged before the quotient planes.
+_GLOO_ROWS_WORKER = _GLOO_PRELUDE + r"""
+import ctypes, torch
+N, W, CH, NCZ = 8, 5, 2, 4
+witness = (np.arange(W * N, dtype=np.uint64).reshape(W, N) + np.uint64(1)) * np.uint64(0x100000001)
+fc = FakeCtx()
+class FakeLib:
+    def lcp2_ntt_batch(self, handle, ptr, ncols, log_n, inverse, coset, mem):  # stand-in "iNTT": x -> 3 x + 1, in place
+        v = fc._at(ptr.value, ncols * N); v[:] = v * np.uint64(3) + np.uint64(1); return 0
+fc.lib, fc.handle, fc._check = FakeLib(), None, (lambda rc: None)
+class FakeParams:
+    cap_height, num_challenges, rate_bits, degree_bits, num_wires = 4, CH, 3, 3, W
+class FakeCirc:
+    params = FakeParams()
+class RowsData:
+    proof_words = 3 * 64 + 40
+    fail_check = False
+    def __init__(self, rank): self.rank, self.qbuf, self.zbuf = rank, np.zeros(64, dtype=np.uint64), np.zeros(NCZ * N, dtype=np.uint64)
+    def _share(self, tag):
+        c = np.zeros((16, 4), dtype=np.uint64)
+        c[8 * self.rank:8 * self.rank + 8] = np.arange(32, dtype=np.uint64).reshape(8, 4) * np.uint64(7) + np.uint64(tag + 100 * self.rank)
+        return c
+    def commit_wires_rows(self, rows_ptr, coeffs_ptr):
+        rows = fc.buffer_read(rows_ptr, W * 4).reshape(W, 4)
+        assert (rows == witness[:, 4 * self.rank:4 * self.rank + 4]).all(), rows          # this rank's rows of EVERY column
+        coeffs = fc.buffer_read(coeffs_ptr, W * N).reshape(W, N)
+        assert (coeffs == witness * np.uint64(3) + np.uint64(1)).all()                    # every column's coefficients
+        return self._share(1)
+    def perm_zs_rows_begin(self, betas, gammas, world):
+        out = np.zeros(world * CH, dtype=np.uint64); out[CH * self.rank:CH * self.rank + CH] = [11 + self.rank, 21 + self.rank]; return out
+    def perm_zs_rows_finish(self, products):
+        assert list(products) == [11, 21, 12, 22]
+        z = self.zbuf.reshape(2, NCZ, 4); z[self.rank] = np.arange(NCZ * 4, dtype=np.uint64).reshape(NCZ, 4) + np.uint64(1000 * (self.rank + 1))
+        return self.zbuf.ctypes.data, self.zbuf.size
+    def perm_zs_commit(self):
+        want = np.stack([np.arange(NCZ * 4, dtype=np.uint64).reshape(NCZ, 4) + np.uint64(1000 * (r + 1)) for r in range(2)])
+        assert (self.zbuf.reshape(2, NCZ, 4) == want).all()
+        return self._share(2)
+    def quotient_values(self, alphas, pi_hash):
+        if self.fail_check and self.rank == 1: raise m.binding.Lcp2Error(m.binding.E_UNSAT, "row 5")
+        for c in range(2): self.qbuf[32 * c + 16 * self.rank:32 * c + 16 * self.rank + 16] = np.uint64(7 + c)
+    def quotient_buffer(self): return (self.qbuf.ctypes.data, self.qbuf.size)
+    def quotient_commit(self): assert (self.qbuf != 0).all(); return self._share(3)
+    def proof_section(self, which): return {0: (192, 8), 1: (200, 4), 2: (192, 40)}[which]
+    def fri_open_begin(self, zeta, state, proof): proof[192 + 4 * self.rank:196 + 4 * self.rank] = 5
+    def fri_open_commit(self, proof): proof[200 + 2 * self.rank:202 + 2 * self.rank] = 6
+    def fri_open_finish(self, proof): proof[212 + 10 * self.rank:222 + 10 * self.rank] = 9
+class RowsComm(m.parallel.TorchComm):  # the library buffers of the stand-in are numpy arrays
+    def _view(self, ptr, words):
+        for a in (sp.data.qbuf, sp.data.zbuf):
+            if a.ctypes.data <= ptr < a.ctypes.data + 8 * a.size: return torch.from_numpy(a.view(np.int64))[(ptr - a.ctypes.data) // 8:][:words]
+        return torch.from_numpy(fc._at(ptr, words).view(np.int64))
+    def all_gather_device(self, ptr, total_words, words_per_rank):
+        self.all_gather_tensor(self._view(ptr, total_words), rank); self.bytes_gathered += 8 * words_per_rank
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        self.dist.all_to_all_single(self._view(recv_ptr, 2 * words_per_pair), self._view(send_ptr, 2 * words_per_pair).clone())
+        self.bytes_gathered += 8 * words_per_pair
+sp = object.__new__(m.parallel.ShardedProver)
+sp.b, sp.ctx, sp.circ, sp.rank, sp.world, sp.comm = m.binding, fc, FakeCirc(), rank, 2, RowsComm(dist)
+sp._vals = sp._coeffs = sp._row_bufs = None
+sp.data = RowsData(rank)
+sp.digest = np.arange(4, dtype=np.uint64)
+first, end = sp.column_shard()
+assert (first, end) == ((0, 3), (3, 5))[rank]
+proof = sp.prove(witness[first:end].copy(), np.array([3, 4], dtype=np.uint64), sharded_columns=True, row_exchange=True)
+gathered = [None, None]
+dist.all_gather_object(gathered, proof.tobytes())
+assert gathered[0] == gathered[1] and (proof[:192].reshape(3, 16, 4) != 0).all()
+# received: coefficients of the other rank's slot (3 columns of 8), its row blocks (3 x 4), half of the Z buffer, half of both planes
+assert sp.comm.bytes_gathered == 8 * (3 * 8 + 3 * 4 + NCZ * 4 + 32), sp.comm.bytes_gathered
+# a gate violation found by one rank stops both, after the verdict exchange and before the next collective
+sp.data.fail_check = True
+try:
+    sp.prove(witness[first:end].copy(), np.array([3, 4], dtype=np.uint64), sharded_columns=True, row_exchange=True)
+    raise SystemExit("an unsatisfied row on rank 1 went unnoticed on rank %d" % rank)
+except m.binding.Lcp2Error as e:
+    assert e.status == m.binding.E_UNSAT and (("row 5" in str(e)) == (rank == 1))
+dist.barrier()
+sp.data = None
+m.parallel.ShardedProver.close  # (buffers of the stand-in context are numpy arrays: nothing to free on a device)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def _run_gloo_pair(tmp_path, text):
+    script = tmp_path / "worker.py"
+    script.write_text(text)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_row_exchange_over_gloo(tmp_path):
+    """world_size-2 gloo: the all-to-all of row blocks, the all-gather of the Z / partial-product rows, the block-product and
+    gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True)"""
+    _run_gloo_pair(tmp_path, _GLOO_ROWS_WORKER)
