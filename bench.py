@@ -140,13 +140,14 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     n = 1 << circ.params.degree_bits
     first, end = prover.column_shard()
     shard_ptr = w_dev.data_ptr() + 8 * first * n
+    rows = bool(comm.row_exchange_ok) and os.environ.get("LCP2_SHARDED_WHOLE_COLUMNS", "0") != "1"
     times = []
     for it in range(reps + 1):
         torch.cuda.synchronize()
         dist.barrier()
         comm.bytes_gathered = 0
         t0 = time.perf_counter()
-        proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True)
+        proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True, row_exchange=rows)
         torch.cuda.synchronize()
         dist.barrier()
         if it:  # the first proof warms RCCL's channels up
@@ -162,8 +163,12 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     n_words = 1 << (circ.params.degree_bits + circ.params.rate_bits)
     return {"workload": "configs[3]: the same n=2^%d proof sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
             "ms_per_proof": float(tt.item()) * 1e3, "world": world, "rccl_world_size": dist.get_world_size(), "proof_verified": ok,
-            "all_gather_form": form, "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
-            "exchange": "RCCL all_gather_into_tensor (in place): witness values, witness coefficients, %d quotient planes; all_reduce(SUM) of 3 caps and the proof array" % circ.params.num_challenges}
+            "all_gather_form": form, "witness_values_exchange": "all-to-all of row blocks" if rows else "all-gather of whole columns",
+            "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
+            "exchange": ("RCCL all_gather_into_tensor (in place): witness coefficients, %s, %d planes of per-coset quotient interpolants; %s"
+                         "all_reduce(SUM) of 3 caps and the proof array")
+                        % ("Z / partial-product rows" if rows else "witness values", circ.params.num_challenges,
+                           "all_to_all_single: witness values as row blocks; " if rows else "")}
 
 
 def parse():

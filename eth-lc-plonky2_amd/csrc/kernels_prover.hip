@@ -173,6 +173,29 @@ __global__ __launch_bounds__(256) void k_perm_finalize(PermArgs a) {
     a.zs_out[((u64)a.num_challenges + (u64)ch * npp + k) * a.n + row] = acc;
   }
 }
+// Coset-sharded proof: the quotient chunks out of the per-coset interpolants.  in[c][b * n + l] is coefficient l of the polynomial
+// of degree < n that agrees with challenge c's quotient on leaf block b (the coset of shift s_b); the quotient is
+// sum_k x^(k n) Q_k(x) and x^n = s_b^n on that coset, so the interpolants are a size-R transform of the chunks Q_k, coefficient by
+// coefficient, and out[c][k * n + l] = sum_b m[k][b] in[c][b * n + l] with the inverse matrix m (prover.hip).
+__global__ __launch_bounds__(256) void k_quotient_combine(const u64 *__restrict__ in, u64 *__restrict__ out, const u64 *__restrict__ m, u64 n, u32 R, u64 plane) {
+  const u64 l = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (l >= n) return;
+  const u64 base = (u64)blockIdx.y * plane + l;
+  u64 r[8];
+#pragma unroll
+  for (u32 b = 0; b < 8; b++) r[b] = b < R ? in[base + (u64)b * n] : 0;
+  for (u32 k = 0; k < R; k++) {
+    u64 acc = 0;
+#pragma unroll
+    for (u32 b = 0; b < 8; b++)
+      if (b < R) acc = gl_add(acc, gl_mul(m[k * R + b], r[b]));
+    out[base + (u64)k * n] = acc;
+  }
+}
+void launch_quotient_combine(hipStream_t s, const u64 *in, u64 *out, const u64 *m, u64 n, u32 R, u64 plane, u32 num_challenges) {
+  hipLaunchKernelGGL(k_quotient_combine, dim3((unsigned)((n + 255) / 256), num_challenges), dim3(256), 0, s, in, out, m, n, R, plane);
+}
+
 void launch_perm_chunks(hipStream_t s, const PermArgs &a) {
   hipLaunchKernelGGL(k_perm_chunks, dim3((unsigned)((a.n + 255) / 256), a.num_challenges), dim3(256), 0, s, a);
 }

@@ -62,6 +62,10 @@ struct lcp2_circuit {
   bool rows_mode = false, cs_rows_ready = false;
   DevBuf cs_rows;   // the constants on this rank's rows, [num_constants][rows()]
   DevBuf zs_rows;   // exchange buffer of Z / partial products, [world][num_challenges * (1 + npp)][rows()]
+  // a sharded circuit with at most 8 blocks interpolates the quotient coset by coset (each rank its own blocks, before the
+  // exchange of the planes) and combines the interpolants into the chunks afterwards: no rank transforms 2^rate_bits n points
+  DevBuf q_combine;  // the combining matrix [R][R] (k_quotient_combine)
+  bool local_quotient() const { return sharded() && p.rate_bits <= 3; }
   u64 perm_wrap[2 * QUOTIENT_MAX_CH] = {0};  // per challenge: Z before the block's last row, the last row's quotient (host)
   uint32_t world() const { return bc ? (1u << p.rate_bits) / bc : 1; }
   uint32_t rank() const { return bc ? bf / bc : 0; }
@@ -718,6 +722,14 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     launch_quotient(s, a, c->dev_gates);
   }
   LCP2_HIP(ctx, hipGetLastError());
+  if (c->local_quotient()) {  // block b is the coset of shift g w_N^bitrev(b), its values in bit-reversed order: interpolate in place
+    ProfScope ps(ctx, LCP2_K_INTT, 16.0 * n * CH * c->nblocks());
+    for (u32 b = c->bf; b < c->bf + c->nblocks(); b++) {
+      const u64 shift = gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity(lgN), bitrev32(b, p.rate_bits)));
+      ntt.inverse_bitrev_in(c->qvals.u() + (u64)b * n, N, c->qvals.u() + (u64)b * n, N, p.degree_bits, CH, shift);
+    }
+    if (be.status) return be.status;
+  }
   u64 bad_row = ~0ull;
   LCP2_TRY(download(ctx, &bad_row, d_small + SMALL_CHECK, 8));  // synchronises the stream
   if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1 + c->row0()));
@@ -730,7 +742,22 @@ int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
   LCP2_STAGE_PROLOGUE
   if (c->stage != lcp2_circuit::ST_QVALS) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient_commit: no quotient values");
   LCP2_HIP(ctx, c->quot.coeffs.ensure((size_t)CH * N * 8));
-  {
+  if (c->local_quotient()) {
+    const u32 R = 1u << p.rate_bits;
+    if (!c->q_combine.p) {
+      // interpolant_b = sum_k (s_b^n)^k Q_k with s_b^n = g^n w_R^bitrev(b)  =>  Q_k = g^(-n k) / R * sum_b w_R^(-bitrev(b) k) interpolant_b
+      std::vector<u64> m((size_t)R * R);
+      const u64 gninv = gl_inv(gl_pow(GL_GENERATOR, n)), wrinv = gl_inv(gl_root_of_unity(p.rate_bits)), rinv = gl_inv(R);
+      for (u32 k = 0; k < R; k++)
+        for (u32 b = 0; b < R; b++)
+          m[(size_t)k * R + b] = gl_mul(gl_mul(gl_pow(gninv, k), rinv), gl_pow(wrinv, (u64)bitrev32(b, p.rate_bits) * k));
+      LCP2_TRY(upload(ctx, c->q_combine, m.data(), m.size() * 8));
+      LCP2_HIP(ctx, hipStreamSynchronize(s));  // `m` is a stack-lifetime staging buffer
+    }
+    ProfScope ps(ctx, LCP2_K_INTT, 16.0 * N * CH);
+    launch_quotient_combine(s, c->qvals.u(), c->quot.coeffs.u(), c->q_combine.u(), n, R, N, CH);
+    LCP2_HIP(ctx, hipGetLastError());
+  } else {
     ProfScope ps(ctx, LCP2_K_INTT, 16.0 * N * CH);
     ntt.inverse_bitrev_in(c->qvals.u(), N, c->quot.coeffs.u(), N, lgN, CH, GL_GENERATOR);
   }

@@ -105,6 +105,7 @@ struct PowArgs {
 
 void launch_scan(hipStream_t s, bool mul, const u64 *in, u64 *out, u64 *block_tot, u64 n, bool reverse, u32 batches, u64 batch_stride);
 u64 scan_scratch_words(u64 n, u32 batches);
+void launch_quotient_combine(hipStream_t s, const u64 *in, u64 *out, const u64 *m, u64 n, u32 R, u64 plane, u32 num_challenges);
 void launch_perm_chunks(hipStream_t s, const PermArgs &a);
 void launch_perm_finalize(hipStream_t s, const PermArgs &a);
 void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates);

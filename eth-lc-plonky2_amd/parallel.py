@@ -315,7 +315,8 @@ class TorchComm:
         import os
         self.dist, self.device, self.ctx = dist, device, ctx
         self.staged = bool(int(os.environ.get("LCP2_SHARDED_STAGED", "0"))) if staged is None else bool(staged)
-        self.bytes_gathered = 0  # received by this rank through all_gather_device (exchange accounting of the bench)
+        self.bytes_gathered = 0  # received by this rank through all_gather_device / all_to_all_device (exchange accounting of the bench)
+        self.row_exchange_ok = True  # self_check(): the all-to-all of the row exchange form reproduces a known answer
 
     def sum_host(self, arr):
         import torch
@@ -357,13 +358,44 @@ class TorchComm:
         self.ctx.sync()
         send = torch.as_tensor(_DevicePtr(send_ptr, world * words_per_pair), device=self.device)
         recv = torch.as_tensor(_DevicePtr(recv_ptr, world * words_per_pair), device=self.device)
-        self.dist.all_to_all_single(recv, send)
+        if self.staged:  # torch-owned tensors on both sides
+            tmp = torch.empty_like(recv)
+            self.dist.all_to_all_single(tmp, send.clone())
+            recv.copy_(tmp)
+        else:
+            self.dist.all_to_all_single(recv, send)
         torch.cuda.synchronize(self.device)
         self.bytes_gathered += 8 * words_per_pair * (world - 1)
 
+    def _check_all_to_all(self, words_per_pair):
+        """known-answer all-to-all on library buffers; the verdict is the same on every rank"""
+        world, rank = self.dist.get_world_size(), self.dist.get_rank()
+        send, recv = self.ctx.buffer_alloc(world * words_per_pair), self.ctx.buffer_alloc(world * words_per_pair)
+        word = lambda src, dst: np.arange(words_per_pair, dtype=np.uint64) * np.uint64(40503) + np.uint64(1000 * src + dst + 1)
+        try:
+            self.ctx.buffer_write(send, np.concatenate([word(rank, d) for d in range(world)]))
+            self.ctx.buffer_write(recv, np.zeros(world * words_per_pair, dtype=np.uint64))
+            before = self.bytes_gathered
+            try:
+                self.all_to_all_device(send, recv, words_per_pair)
+                good = bool((self.ctx.buffer_read(recv, world * words_per_pair) == np.concatenate([word(s, rank) for s in range(world)])).all())
+            except RuntimeError:
+                good = False
+            self.bytes_gathered = before
+            return int(self.sum_host(np.array([0 if good else 1], dtype=np.uint64))[0]) == 0
+        finally:
+            self.ctx.buffer_free(send)
+            self.ctx.buffer_free(recv)
+
     def self_check(self, words_per_rank=1 << 16):
         """Known-answer all-gather on a library buffer.  Returns "in-place" or "staged" (the form that will be used), raises if
-        neither reproduces what the ranks wrote."""
+        neither reproduces what the ranks wrote.  Also tries the all-to-all of the row exchange form: `row_exchange_ok` says
+        whether ShardedProver.prove(..., row_exchange=True) can be used (the whole-column form needs all-gathers only)."""
+        form = self._check_all_gather(words_per_rank)
+        self.row_exchange_ok = self._check_all_to_all(max(words_per_rank // 16, 1))
+        return form
+
+    def _check_all_gather(self, words_per_rank):
         world, rank = self.dist.get_world_size(), self.dist.get_rank()
         buf = self.ctx.buffer_alloc(world * words_per_rank)
         want = np.concatenate([(np.arange(words_per_rank, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(r + 1)) for r in range(world)])

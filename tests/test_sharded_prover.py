@@ -397,8 +397,18 @@ class CheckComm(m.parallel.TorchComm):
         self.all_gather_tensor(view, rank)
         if not self.staged and self.broken and rank == 1: view[3] += 1   # the aliased form "returns wrong data" on one rank only
         self.bytes_gathered += 8 * words_per_rank
+    a2a_broken = False
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        send = torch.from_numpy(self.ctx._at(send_ptr, 2 * words_per_pair).view(np.int64)).clone()
+        recv = torch.from_numpy(self.ctx._at(recv_ptr, 2 * words_per_pair).view(np.int64))
+        self.dist.all_to_all_single(recv, send)
+        if self.a2a_broken and rank == 0: recv[1] ^= 1
+        self.bytes_gathered += 8 * words_per_pair
 fc = FakeCtx()
-assert CheckComm(dist, None, fc).self_check(256) == "in-place"
+cc = CheckComm(dist, None, fc)
+assert cc.self_check(256) == "in-place" and cc.row_exchange_ok and cc.bytes_gathered == 0
+cc = CheckComm(dist, None, fc); cc.a2a_broken = True   # wrong data on one rank: both ranks give the row exchange form up
+assert cc.self_check(256) == "in-place" and not cc.row_exchange_ok
 assert CheckComm(dist, None, fc, staged=True).self_check(256) == "staged"
 for attr in ("broken", "refuse"):
     cc = CheckComm(dist, None, fc); setattr(cc, attr, True)

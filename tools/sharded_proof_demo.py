@@ -24,21 +24,50 @@ class _Solo:  # N = 1: the collectives are the identity
     def all_gather_device(self, ptr, total_words, words_per_rank):
         pass
 
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        raise RuntimeError("the row exchange form needs more than one rank (or --rehearse)")
+
 
 class _Rehearsal(_Solo):
     """rank R of W alone on one GPU: the collectives are the identity except the first all-gather (the witness values), which is
     filled from the whole witness - a rank checks the witness it proves, so the values must be the real ones.  The time spent in
     here is not the rank's compute."""
 
-    def __init__(self, m, ctx, d_wires, num_wires, n, world):
+    def __init__(self, m, ctx, d_wires, num_wires, n, world, rank=0, row_exchange=False, num_challenges=2):
         self.m, self.ctx, self.d_wires, self.n, self.calls, self.seconds = m, ctx, d_wires, n, 0, 0.0
         self.shards = m.parallel.column_shards(num_wires, world)
+        self.world, self.rank, self.row_exchange, self.ch = world, rank, row_exchange, num_challenges
+
+    def sum_host(self, a):
+        # row exchange form: the table of block products must multiply to 1 (lcp2_perm_zs_rows_finish checks the copy constraints
+        # with it); the other ranks' entries are made up so that it does
+        if self.row_exchange and a.size == self.world * self.ch and a.ndim == 1 and self.world > 1:
+            P = self.m.GOLDILOCKS_P
+            out = a.copy()
+            other = (self.rank + 1) % self.world
+            for r in range(self.world):
+                for k in range(self.ch):
+                    if r != self.rank:
+                        out[r * self.ch + k] = pow(int(a[self.rank * self.ch + k]), P - 2, P) if r == other else 1
+            return out
+        return a
+
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        """this rank's rows of EVERY column, out of the whole witness (the rank checks the gates on them)"""
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.time()
+        rows = self.n // self.world
+        for r, (s, e) in enumerate(self.shards):
+            self.ctx.buffer_copy_2d(recv_ptr + 8 * r * words_per_pair, rows, self.d_wires.data_ptr() + 8 * (s * self.n + self.rank * rows), self.n, rows, e - s)
+        torch.cuda.synchronize()
+        self.seconds += time.time() - t0
 
     def all_gather_device(self, ptr, total_words, words_per_rank):
         import torch
         torch.cuda.synchronize()
         t0 = time.time()
-        if self.calls == 0:
+        if self.calls == 0 and not self.row_exchange:
             for r, (s, e) in enumerate(self.shards):
                 self.ctx.buffer_copy(ptr + 8 * r * words_per_rank, self.d_wires.data_ptr() + 8 * s * self.n, (e - s) * self.n)
         self.calls += 1
@@ -51,6 +80,8 @@ def main():
     ap.add_argument("--degree-bits", type=int, default=22)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sharded-columns", action="store_true", help="the witness arrives column-sharded (all-gather of values and coefficients)")
+    ap.add_argument("--row-exchange", action="store_true", help="with --sharded-columns: the values cross the ranks as row blocks "
+                    "(all-to-all), K5 and the gate check run on a rank's own rows (include/lcp2.h, the row exchange form)")
     ap.add_argument("--rehearse", default="", help="R/W: time the compute of rank R of W on this one GPU (collectives replaced by "
                     "the identity, so the transcript is not the real one and the proof is not verified)")
     a = ap.parse_args()
@@ -76,7 +107,7 @@ def main():
     d_wires = torch.from_numpy(wires.view("int64")).cuda()  # witness resident in HBM, as in bench.py
     n = 1 << a.degree_bits
     if rehearse and a.sharded_columns:
-        prover.comm = comm = _Rehearsal(m, ctx, d_wires, params.num_wires, n, world)
+        prover.comm = comm = _Rehearsal(m, ctx, d_wires, params.num_wires, n, world, rank, a.row_exchange, params.num_challenges)
     first, end = prover.column_shard()
     mine = d_wires[first:end].contiguous() if a.sharded_columns else d_wires
     times = []
@@ -89,14 +120,14 @@ def main():
         ctx.prof_reset()
         torch.cuda.synchronize()
         t0 = time.time()
-        proof = prover.prove(mine.data_ptr(), pis, mem=m.MEM_DEVICE, sharded_columns=a.sharded_columns)
+        proof = prover.prove(mine.data_ptr(), pis, mem=m.MEM_DEVICE, sharded_columns=a.sharded_columns, row_exchange=a.row_exchange)
         torch.cuda.synchronize()
         times.append(time.time() - t0 - (comm.seconds if isinstance(comm, _Rehearsal) else 0.0))
     fam = ", ".join("%s %.1f" % (k, v["ms"]) for k, v in ctx.prof_get().items() if v["ms"] > 0.05)
     if rehearse:
         print("rehearsal of rank %d of %d, degree_bits %d%s: build %.2f s, per-rank compute of a sharded proof %s ms (exchanges excluded); "
               "kernel families of the last proof (ms): %s"
-              % (rank, world, a.degree_bits, ", column-sharded witness" if a.sharded_columns else "", build_s,
+              % (rank, world, a.degree_bits, (", column-sharded witness" + (", row exchange" if a.row_exchange else "")) if a.sharded_columns else "", build_s,
                  ", ".join("%.1f" % (1e3 * t) for t in times), fam))
         return
     if rank == 0:
