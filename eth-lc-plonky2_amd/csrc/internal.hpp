@@ -93,6 +93,7 @@ void launch_merkle_level(hipStream_t s, const u64 *children, u64 *parents, u64 n
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz);
 void launch_bitrev_tile(hipStream_t s, const BitrevTile &b, u32 wgs, u32 cols);
 void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os, u32 lg, u32 cols, unsigned long long *noncanonical = nullptr);
+void launch_copy_2d(hipStream_t s, u64 *dst, u64 dst_pitch_words, const u64 *src, u64 src_pitch_words, u64 width_words, u32 height);
 void launch_canon_copy(hipStream_t s, const u64 *in, u64 *out /* nullable: scan only */, u64 count, unsigned long long *noncanonical);
 void launch_sha256_level(hipStream_t s, const uint8_t *children, uint8_t *parents, u64 nparents_per_tree, u64 trees,
                          u64 child_tree_stride, u64 parent_tree_stride, uint32_t *trace, u64 trace_tree_stride,

@@ -170,6 +170,17 @@ void launch_bitrev_small(hipStream_t s, const u64 *in, u64 is, u64 *out, u64 os,
   u32 blocks = (n + 255) / 256;
   hipLaunchKernelGGL(k_bitrev_small, dim3(blocks, cols), dim3(256), 0, s, in, is, out, os, lg, noncanonical);
 }
+// `height` runs of `width` words, the pitches (in words) apart: row blocks out of / into whole columns
+__global__ __launch_bounds__(256) void k_copy_2d(u64 *__restrict__ dst, u64 dst_pitch, const u64 *__restrict__ src, u64 src_pitch, u64 width) {
+  const u64 h = blockIdx.y;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (u64)gridDim.x * blockDim.x) dst[h * dst_pitch + i] = src[h * src_pitch + i];
+}
+void launch_copy_2d(hipStream_t s, u64 *dst, u64 dst_pitch, const u64 *src, u64 src_pitch, u64 width, u32 height) {
+  if (!width || !height) return;
+  const u64 want = (width + 255) / 256;
+  hipLaunchKernelGGL(k_copy_2d, dim3((unsigned)(want < 4096 ? want : 4096), height), dim3(256), 0, s, dst, dst_pitch, src, src_pitch, width);
+}
+
 void launch_canon_copy(hipStream_t s, const u64 *in, u64 *out, u64 count, unsigned long long *noncanonical) {
   const u64 want = (count + 255) / 256;
   hipLaunchKernelGGL(k_canon_copy, dim3((unsigned)(want < 8192 ? (want ? want : 1) : 8192)), dim3(256), 0, s, in, out, count, noncanonical);

@@ -599,10 +599,12 @@ extern "C" int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_sr
   return LCP2_OK;
 }
 extern "C" int lcp2_buffer_copy_2d(lcp2_ctx *ctx, void *dev_dst, size_t dst_pitch, const void *dev_src, size_t src_pitch, size_t width, size_t height) {
-  if (!ctx || !dev_dst || !dev_src || width > dst_pitch || width > src_pitch) return LCP2_E_INVALID;
+  if (!ctx || !dev_dst || !dev_src || width > dst_pitch || width > src_pitch || height > 65535) return LCP2_E_INVALID;
+  if ((dst_pitch | src_pitch | width | (size_t)dev_dst | (size_t)dev_src) & 7) return LCP2_E_INVALID;  // whole field elements
   if (width == 0 || height == 0) return LCP2_OK;
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
-  LCP2_HIP(ctx, hipMemcpy2DAsync(dev_dst, dst_pitch, dev_src, src_pitch, width, height, hipMemcpyDeviceToDevice, ctx->stream));
+  launch_copy_2d(ctx->stream, (u64 *)dev_dst, dst_pitch / 8, (const u64 *)dev_src, src_pitch / 8, width / 8, (u32)height);
+  LCP2_HIP(ctx, hipGetLastError());
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LCP2_OK;
 }

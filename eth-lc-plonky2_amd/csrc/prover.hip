@@ -554,7 +554,7 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
     if (rows_only && !c->cs_rows_ready) {  // the gate check reads the constants with the stride of the wires
       const u64 R = c->rows();
       LCP2_HIP(ctx, c->cs_rows.ensure((size_t)NC * R * 8));
-      LCP2_HIP(ctx, hipMemcpy2DAsync(c->cs_rows.p, R * 8, c->cs_values.u() + c->row0(), n * 8, R * 8, NC, hipMemcpyDeviceToDevice, s));
+      launch_copy_2d(s, c->cs_rows.u(), R, c->cs_values.u() + c->row0(), n, R, NC);
       c->cs_rows_ready = true;
     }
   } else {
@@ -647,7 +647,7 @@ int perm_commit(lcp2_circuit *c, u64 *cap_out) {
   if (c->rows_mode) {  // the exchange buffer holds every rank's rows, [rank][column][rows]: back to whole columns
     const u64 R = c->rows();
     for (u32 r = 0; r < c->world(); r++)
-      LCP2_HIP(ctx, hipMemcpy2DAsync(c->zs_vals.u() + (u64)r * R, n * 8, c->zs_rows.u() + (u64)r * ncz * R, R * 8, R * 8, ncz, hipMemcpyDeviceToDevice, s));
+      launch_copy_2d(s, c->zs_vals.u() + (u64)r * R, n, c->zs_rows.u() + (u64)r * ncz * R, R, R, ncz);
   }
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), ncz, p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
   LCP2_TRY(download_cap(c, c->zs, cap_out));  // synchronises the stream

@@ -311,6 +311,11 @@ class TorchComm:
     known contents first and falls back to the staged form if the result is not what every rank wrote - the in-place form over
     RCCL with more than one rank has not run on hardware yet."""
 
+    # Message sizes beyond these go in pieces: collectives with more than 1 GiB per peer are the rare case in RCCL's use (and its
+    # one-rank all-to-all demonstrably mishandles them, tools/rccl_a2a_probe.py); at 8 ranks and n = 2^22 nothing is split
+    A2A_WORDS_PER_PAIR = 1 << 26     # 512 MiB per pair
+    GATHER_WORDS_PER_RANK = 1 << 27  # 1 GiB per rank
+
     def __init__(self, dist, device=None, ctx=None, staged=None):
         import os
         self.dist, self.device, self.ctx = dist, device, ctx
@@ -329,8 +334,18 @@ class TorchComm:
     def all_gather_tensor(self, out, rank):
         """all-gather on a 1-D tensor whose part r is out[r * k : (r + 1) * k].  In place over RCCL (it recognises the aliasing
         and moves every byte once); gloo and the staged form get a private copy of the input."""
-        k = out.numel() // self.dist.get_world_size()
+        world = self.dist.get_world_size()
+        k = out.numel() // world
         mine = out[rank * k:(rank + 1) * k]
+        if world > 1 and k > self.GATHER_WORDS_PER_RANK:  # parts above 1 GiB in pieces, each through a staging tensor
+            import torch
+            for off in range(0, k, self.GATHER_WORDS_PER_RANK):
+                end = min(off + self.GATHER_WORDS_PER_RANK, k)
+                got = torch.empty(world * (end - off), dtype=out.dtype, device=out.device)
+                self.dist.all_gather_into_tensor(got, mine[off:end].clone())
+                for r in range(world):
+                    out[r * k + off:r * k + end].copy_(got[r * (end - off):(r + 1) * (end - off)])
+            return
         if self.staged:
             import torch
             tmp = torch.empty_like(out)
@@ -351,19 +366,37 @@ class TorchComm:
         torch.cuda.synchronize(self.device)
         self.bytes_gathered += 8 * words_per_rank * (world - 1)
 
+    def all_to_all_tensor(self, recv, send):
+        """part d of `send` goes to rank d, part s of `recv` comes from rank s (1-D tensors of world * k words)"""
+        world = self.dist.get_world_size()
+        k = send.numel() // world
+        if world == 1:
+            recv.copy_(send)  # (RCCL 2.26's one-rank all-to-all moves only half of a message above 1 GiB: tools/rccl_a2a_probe.py)
+        elif self.staged:  # torch-owned tensors on both sides
+            import torch
+            tmp = torch.empty_like(recv)
+            self.dist.all_to_all_single(tmp, send.clone())
+            recv.copy_(tmp)
+        elif k <= self.A2A_WORDS_PER_PAIR:
+            self.dist.all_to_all_single(recv, send)
+        else:  # large messages in pieces, each through a packed staging pair
+            import torch
+            for off in range(0, k, self.A2A_WORDS_PER_PAIR):
+                end = min(off + self.A2A_WORDS_PER_PAIR, k)
+                packed = torch.cat([send[d * k + off:d * k + end] for d in range(world)])
+                got = torch.empty_like(packed)
+                self.dist.all_to_all_single(got, packed)
+                for src in range(world):
+                    recv[src * k + off:src * k + end].copy_(got[src * (end - off):(src + 1) * (end - off)])
+
     def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
-        """part d of the send buffer goes to rank d; part s of the receive buffer comes from rank s (both library buffers)"""
+        """all_to_all_tensor on two library buffers"""
         import torch
         world = self.dist.get_world_size()
         self.ctx.sync()
         send = torch.as_tensor(_DevicePtr(send_ptr, world * words_per_pair), device=self.device)
         recv = torch.as_tensor(_DevicePtr(recv_ptr, world * words_per_pair), device=self.device)
-        if self.staged:  # torch-owned tensors on both sides
-            tmp = torch.empty_like(recv)
-            self.dist.all_to_all_single(tmp, send.clone())
-            recv.copy_(tmp)
-        else:
-            self.dist.all_to_all_single(recv, send)
+        self.all_to_all_tensor(recv, send)
         torch.cuda.synchronize(self.device)
         self.bytes_gathered += 8 * words_per_pair * (world - 1)
 

@@ -173,7 +173,8 @@ int lcp2_buffer_zero(lcp2_ctx *ctx, void *dev, size_t bytes);
 int lcp2_buffer_read(lcp2_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 int lcp2_buffer_write(lcp2_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int lcp2_buffer_copy(lcp2_ctx *ctx, void *dev_dst, const void *dev_src, size_t bytes);   /* device to device, on the context's stream */
-/* `height` runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart (device to device): row blocks out of / into columns */
+/* `height` (< 65536) runs of `width` bytes, `src_pitch` / `dst_pitch` bytes apart (device to device; everything a multiple of 8):
+ * row blocks out of / into whole columns */
 int lcp2_buffer_copy_2d(lcp2_ctx *ctx, void *dev_dst, size_t dst_pitch, const void *dev_src, size_t src_pitch, size_t width, size_t height);
 
 /* ------------------------------------------------------------------ polynomial commitments

@@ -119,7 +119,7 @@ def test_sharded_columns_with_a_short_middle_shard(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 6, 135), (8, 5, 135), (8, 4, 135), (8, 7, 140)])
+@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 6, 135), (8, 5, 135), (8, 4, 135), (8, 7, 140), (1, 9, 135)])
 def test_row_exchange_proof_equals_single_gpu(gpu_ctx, world, degree_bits, num_wires):
     """the row exchange form (include/lcp2.h): the witness values cross the ranks as row blocks, K5 and the gate check run on a
     rank's own rows, the Z / partial-product rows are all-gathered.  (8, 4): two rows per rank; (8, 7, 140): gaps in the padded
@@ -221,6 +221,31 @@ def test_row_exchange_reports_an_unsatisfied_witness_on_every_rank(gpu_ctx):
         for r in ranks:
             r.close()
     single.close()
+
+
+@pytest.mark.gpu
+def test_buffer_copy_2d(gpu_ctx):
+    """lcp2_buffer_copy_2d: row blocks out of whole columns and back, incl. runs of 2^22 words (the one-rank row exchange at the
+    headline size copies whole columns with it)"""
+    import eth_lc_plonky2_amd as m
+    rng = np.random.default_rng(5)
+    for cols, n, world in ((7, 64, 4), (3, 1 << 22, 1), (5, 1 << 16, 8)):
+        rows = n // world
+        a = rng.integers(0, 2 ** 63, size=(cols, n), dtype=np.uint64)
+        src, dst = gpu_ctx.buffer_alloc(cols * n), gpu_ctx.buffer_alloc(cols * n)
+        gpu_ctx.buffer_write(src, a)
+        for d in range(world):  # [column][n] -> [rank][column][rows]
+            gpu_ctx.buffer_copy_2d(dst + 8 * d * cols * rows, rows, src + 8 * d * rows, n, rows, cols)
+        got = gpu_ctx.buffer_read(dst, cols * n).reshape(world, cols, rows)
+        assert all((got[d] == a[:, d * rows:(d + 1) * rows]).all() for d in range(world))
+        gpu_ctx.buffer_free(src)
+        gpu_ctx.buffer_free(dst)
+    with pytest.raises(m.Lcp2Error):
+        p = gpu_ctx.buffer_alloc(64)
+        try:
+            gpu_ctx.buffer_copy_2d(p, 4, p + 256, 8, 8, 2)  # runs wider than the destination pitch
+        finally:
+            gpu_ctx.buffer_free(p)
 
 
 @pytest.mark.gpu
@@ -499,7 +524,7 @@ class RowsComm(m.parallel.TorchComm):  # the library buffers of the stand-in are
     def all_gather_device(self, ptr, total_words, words_per_rank):
         self.all_gather_tensor(self._view(ptr, total_words), rank); self.bytes_gathered += 8 * words_per_rank
     def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
-        self.dist.all_to_all_single(self._view(recv_ptr, 2 * words_per_pair), self._view(send_ptr, 2 * words_per_pair).clone())
+        self.all_to_all_tensor(self._view(recv_ptr, 2 * words_per_pair), self._view(send_ptr, 2 * words_per_pair))
         self.bytes_gathered += 8 * words_per_pair
 sp = object.__new__(m.parallel.ShardedProver)
 sp.b, sp.ctx, sp.circ, sp.rank, sp.world, sp.comm = m.binding, fc, FakeCirc(), rank, 2, RowsComm(dist)
@@ -514,6 +539,18 @@ dist.all_gather_object(gathered, proof.tobytes())
 assert gathered[0] == gathered[1] and (proof[:192].reshape(3, 16, 4) != 0).all()
 # received: coefficients of the other rank's slot (3 columns of 8), its row blocks (3 x 4), half of the Z buffer, half of both planes
 assert sp.comm.bytes_gathered == 8 * (3 * 8 + 3 * 4 + NCZ * 4 + 32), sp.comm.bytes_gathered
+# the all-to-all primitive on its own: whole, in pieces (a message above the per-pair limit), staged
+for limit, staged in ((1 << 26, False), (5, False), (1 << 26, True)):
+    cm = RowsComm(dist, staged=staged); cm.A2A_WORDS_PER_PAIR = limit
+    snd = torch.arange(24, dtype=torch.int64) + 100 * rank
+    rcv = torch.zeros(24, dtype=torch.int64)
+    cm.all_to_all_tensor(rcv, snd)
+    assert rcv.tolist() == [12 * rank + j for j in range(12)] + [100 + 12 * rank + j for j in range(12)], (limit, staged, rcv.tolist())
+for limit in (1 << 27, 5):  # and the all-gather, whole and in pieces
+    cm = RowsComm(dist); cm.GATHER_WORDS_PER_RANK = limit
+    buf = torch.zeros(24, dtype=torch.int64); buf[12 * rank:12 * rank + 12] = torch.arange(12) + 50 * (rank + 1)
+    cm.all_gather_tensor(buf, rank)
+    assert buf.tolist() == [50 + j for j in range(12)] + [100 + j for j in range(12)], (limit, buf.tolist())
 # a gate violation found by one rank stops both, after the verdict exchange and before the next collective
 sp.data.fail_check = True
 try:
