@@ -362,9 +362,11 @@ int lcp2_hash_no_pad(const uint64_t *values, size_t count, uint64_t out[4]); /* 
  * proof words every rank holds identically come from the rank holding block 0 only - so one SUM all-reduce (uint64 wrap-around;
  * RCCL has no bitwise reductions) of a share assembles the result.  The bulk exchanges are (1) the witness: the ranks may hold
  * column shards, all-gather the values, transform their own columns and all-gather the coefficients (lcp2_commit_wires_coeffs);
- * (2) the quotient values (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer - per challenge
+ * (2) the quotient (num_challenges * 8n words): each rank fills its blocks of lcp2_quotient_buffer - per challenge
  * plane they are one contiguous run at offset block_first * n, in rank order - so an in-place all-gather of each plane
- * completes the buffer (a SUM all-reduce works too: the rest is zeros); then every rank calls lcp2_quotient_commit.
+ * completes the buffer (a SUM all-reduce works too: the rest is zeros); then every rank calls lcp2_quotient_commit.  (What a
+ * block holds is the library's business: with rate_bits <= 3 it is the interpolant of the quotient on the block's coset - a rank
+ * transforms only its own cosets, and lcp2_quotient_commit combines the interpolants into the quotient chunks.)
  * In the opening stage a rank evaluates its share of the columns of every batch (it holds all coefficients) and commits its
  * own leaf blocks of FRI layer 0; folding is done in coefficient form, so no FRI values cross the ranks, and the smaller
  * layers are computed by every rank.
