@@ -49,7 +49,8 @@ __device__ __forceinline__ void lds_barrier() {
 // phase.  The first step runs on the prefetched registers and the last one stores from registers (strided) or through the wave's
 // own LDS region (contiguous): see ntt.hpp.  Barriers per slab: 3 (strided) / 4 (contiguous), LDS round trips 2 / 4.
 // FMODE: coset scale of an LDE's first pass (0 none, 1 one-level table, 2 computed from one table value per thread).
-template <bool STRIDED, int FMODE>
+// SS: the strided shape (4: S 4, B 9, three steps; 7: S 7, B 6, two steps - the first step is followed by the last one directly).
+template <bool STRIDED, int FMODE, u32 SS = 4>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p, u32 gx, u32 gy, u32 gz, u32 slabs_per_wg) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   NttPass pass{p};
@@ -75,28 +76,34 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_pass_pf(NttPassParams p,
   coords(0, wg, col, z);
   pass.prefetch(tid, NTT_THREADS, wg, col, z, v);
   u64 *twl = lds + ntt_lds_words(13);  // compact step twiddles behind the slab (ntt.hpp pf_stage_twiddles); the first barrier publishes them
-  pass.template pf_stage_twiddles<STRIDED>(twl, tid);
+  pass.template pf_stage_twiddles<STRIDED, SS>(twl, tid);
   if (STRIDED) lds_barrier();  // the first step of a strided pass reads them already
   // Everything a phase derives from the thread id alone - 64-bit twiddle addresses above all, two dozen per step - is loop invariant,
   // and hipcc hoists all of it out of the slab loop and then spills it (100 VGPRs of scratch, reloaded for every slab).  The thread
   // id is therefore made opaque once per phase: the addresses are recomputed (one or two instructions each) where they are used.
   auto fresh_tid = [&]() { u32 t = tid; asm volatile("" : "+v"(t)); return t; };
   for (u32 it = 0; it < slabs_per_wg; it++) {
-    pass.template pf_first_step<STRIDED, FMODE>(lds, fresh_tid(), wg, z, v, STRIDED ? twl : p.group_tw);
+    pass.template pf_first_step<STRIDED, FMODE, SS>(lds, fresh_tid(), wg, z, v, STRIDED ? twl : p.group_tw);
     lds_barrier();
     u32 nwg = wg, ncol = col, nz = z;
     if (it + 1 < slabs_per_wg) {
       coords(it + 1, nwg, ncol, nz);
       pass.prefetch(fresh_tid(), NTT_THREADS, nwg, ncol, nz, v);
     }
-    if (STRIDED) {  // S = 4, B = 9: the remaining steps at local bits 7 and 4
+    if (STRIDED && SS == 7) {  // S = 7, B = 6: the remaining step at local bit 7
+      u64 x[16];
+      const u32 t = fresh_tid();
+      pass.template pf_last_strided_read<7>(lds, t, x);
+      lds_barrier();  // the slab has been read out: the next first step may overwrite it
+      pass.template pf_last_strided_store<7>(t, wg, col, z, x);
+    } else if (STRIDED) {  // S = 4, B = 9: the remaining steps at local bits 7 and 4
       pass.template pf_mid_step<7>(lds, fresh_tid(), 5, twl + 512);
       lds_barrier();
       u64 x[16];
       const u32 t = fresh_tid();
-      pass.pf_last_strided_read(lds, t, x);
+      pass.template pf_last_strided_read<4>(lds, t, x);
       lds_barrier();  // the slab has been read out: the next first step may overwrite it
-      pass.pf_last_strided_store(t, wg, col, z, x);
+      pass.template pf_last_strided_store<4>(t, wg, col, z, x);
     } else {        // S = 0, B = 13: 3 + 3 bits at 7 and 4, then the 4 bottom bits
       pass.template pf_mid_step<7>(lds, fresh_tid(), 9, twl);
       lds_barrier();
@@ -147,13 +154,17 @@ void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wg
   if (spw) {
     const dim3 grid((u32)(total / spw));
     lds_bytes += 8 * (ntt_pf_strided(p) ? NttPass::PF_TW_WORDS_STRIDED : NttPass::PF_TW_WORDS_CONTIGUOUS);  // 2 x 77 KiB still share a CU
-#define LCP2_PF(STR, FM) hipLaunchKernelGGL((k_ntt_pass_pf<STR, FM>), grid, dim3(NTT_THREADS), lds_bytes, s, p, wgs, cols, nz, spw)
-    if (ntt_pf_strided(p)) {
-      if (!p.scale_mode) LCP2_PF(true, 0);
-      else if (p.sc_step) LCP2_PF(true, 2);
-      else LCP2_PF(true, 1);
+#define LCP2_PF(STR, FM, SS) hipLaunchKernelGGL((k_ntt_pass_pf<STR, FM, SS>), grid, dim3(NTT_THREADS), lds_bytes, s, p, wgs, cols, nz, spw)
+    if (ntt_pf_strided_s(p) == 7) {
+      if (!p.scale_mode) LCP2_PF(true, 0, 7);
+      else if (p.sc_step) LCP2_PF(true, 2, 7);
+      else LCP2_PF(true, 1, 7);
+    } else if (ntt_pf_strided(p)) {
+      if (!p.scale_mode) LCP2_PF(true, 0, 4);
+      else if (p.sc_step) LCP2_PF(true, 2, 4);
+      else LCP2_PF(true, 1, 4);
     } else {
-      LCP2_PF(false, 0);
+      LCP2_PF(false, 0, 4);
     }
 #undef LCP2_PF
     return;

@@ -258,7 +258,8 @@ struct NttPass {
   }
 
   // ---- The phases of the prefetching kernel (kernels_ntt.hip k_ntt_pass_pf): forward passes over 2^13-element slabs with 512
-  // threads, STRIDED = (S 4, B 9: steps of 3 bits at local bits 10, 7, 4) or contiguous (S 0, B 13: 3 + 3 + 3 + 4 bits).
+  // threads, STRIDED = (S 4, B 9: steps of 3 bits at local bits 10, 7, 4 - the first pass at 2^22; or SS = 7: S 7, B 6: steps at
+  // local bits 10 and 7 - the first pass at 2^19, the size of the light-client step) or contiguous (S 0, B 13: 3 + 3 + 3 + 4 bits).
   // A thread's 16 prefetched elements (local indices tid + 512 k) are exactly two groups of the FIRST register step (k even /
   // k odd: local bits 10..12 = k >> 1), so that step runs on the prefetched registers and the slab reaches LDS already
   // transformed: one LDS round trip and one barrier less than load -> LDS -> step.  Likewise the LAST step of a strided pass
@@ -280,9 +281,11 @@ struct NttPass {
   //   strided    [0, 512)   first step  w_512^e          [512, 576)    step at bit 7  w_64^e
   //   contiguous [0, 1024)  step at bit 7  w_1024^e      [1024, 1152)  step at bit 4  w_128^e   (the first step spans the whole table)
   static constexpr u32 PF_TW_WORDS_STRIDED = 576, PF_TW_WORDS_CONTIGUOUS = 1152;
-  template <bool STRIDED>
+  template <bool STRIDED, u32 SS = 4>
   LCP2_HD void pf_stage_twiddles(u64 *twl, u32 tid) const {
-    if (STRIDED) {
+    if (STRIDED && SS == 7) {
+      if (tid < 64) twl[tid] = p.group_tw[tid];  // w_64^e: the first step; the last one has no step twiddle
+    } else if (STRIDED) {
       twl[tid] = p.group_tw[tid];
       if (tid < 64) twl[512 + tid] = p.group_tw[tid << 3];
     } else {
@@ -293,7 +296,7 @@ struct NttPass {
   }
   // twt: the step twiddles w^(m * bitrev(j)) of the step, indexed by the exponent (p.group_tw itself for the top step, or the
   // workgroup's compact copy in LDS, pf_stage_twiddles)
-  template <bool STRIDED, int FMODE>
+  template <bool STRIDED, int FMODE, u32 SS = 4>
   LCP2_HD void pf_first_step(u64 *lds, u32 tid, u32 wg, u32 z, const u64 *v, const u64 *twt) const {
     constexpr u32 PS = 512 + 32;  // lds_phys(tid + 512 k) = lds_phys(tid) + k * PS
     const u32 ph0 = lds_phys(tid);
@@ -304,7 +307,7 @@ struct NttPass {
     if (FMODE == 2) f0 = fac[0];
 #pragma unroll
     for (u32 b = 0; b < 2; b++) {
-      const u32 m = STRIDED ? ((tid >> 4) | (b << 5)) : (tid | (b << 9));  // group bits below the step
+      const u32 m = STRIDED ? (SS == 7 ? ((tid >> 7) | (b << 2)) : ((tid >> 4) | (b << 5))) : (tid | (b << 9));  // group bits below the step
       u64 x[8], tw[8], f[8];
 #pragma unroll
       for (u32 j = 1; j < 8; j++) tw[j] = twt[m * bitrev32(j, 3)];
@@ -372,31 +375,34 @@ struct NttPass {
 #pragma unroll
     for (u32 j = 0; j < 8; j++) lds[p1 + j * PSTRIDE] = x1[j];
   }
-  // last step of a strided pass (bits 4..6, no step twiddle) in two halves: the LDS reads, then - after the barrier that lets
-  // the next slab in - transform, inter-group twiddle and the global stores from registers
+  // last step of a strided pass (local bits P..P+2 with P = S, no step twiddle) in two halves: the LDS reads, then - after the
+  // barrier that lets the next slab in - transform, inter-group twiddle and the global stores from registers
+  template <u32 P = 4>
   LCP2_HD void pf_last_strided_read(const u64 *lds, u32 tid, u64 *x) const {
+    constexpr u32 PSTRIDE = (1u << P) + (1u << (P - 4));
 #pragma unroll
     for (u32 q = 0; q < 2; q++) {
-      const u32 g = tid + 512 * q, base = ((g >> 4) << 7) | (g & 15), pb = lds_phys(base);
+      const u32 g = tid + 512 * q, base = ((g >> P) << (P + 3)) | (g & ((1u << P) - 1)), pb = lds_phys(base);
 #pragma unroll
-      for (u32 j = 0; j < 8; j++) x[8 * q + j] = lds[pb + j * 17];
+      for (u32 j = 0; j < 8; j++) x[8 * q + j] = lds[pb + j * PSTRIDE];
     }
   }
+  template <u32 P = 4>
   LCP2_HD void pf_last_strided_store(u32 tid, u32 wg, u32 col, u32 z, u64 *x) const {
     u64 *dst = p.out + (u64)col * p.out_col_stride + (u64)(bitrev32(z, p.zbits) - p.out_block_base) * p.out_z_stride;
     const bool direct = p.tw.h == NTT_DIRECT;
 #pragma unroll
     for (u32 q = 0; q < 2; q++) {
-      const u32 g = tid + 512 * q, base = ((g >> 4) << 7) | (g & 15);
-      const u64 g0 = global_index(wg, base), gs = (u64)1 << p.g_lo;  // element j of the group: local base | j << 4, one run further
+      const u32 g = tid + 512 * q, base = ((g >> P) << (P + 3)) | (g & ((1u << P) - 1));
+      const u64 g0 = global_index(wg, base), gs = (u64)1 << p.g_lo;  // element j of the group: local base | j << P, one run further
       u64 tw[8];
       if (direct) {
-        const u64 *fac = p.tw.lo + (((u64)((base >> 4) & 511) << p.g_lo) | low_bits(wg, base));
+        const u64 *fac = p.tw.lo + (((u64)((base >> P) & ((1u << (13 - P)) - 1)) << p.g_lo) | low_bits(wg, base));
 #pragma unroll
         for (u32 j = 0; j < 8; j++) tw[j] = fac[j * gs];
       } else {
 #pragma unroll
-        for (u32 j = 0; j < 8; j++) tw[j] = group_twiddle(wg, base | (j << 4));
+        for (u32 j = 0; j < 8; j++) tw[j] = group_twiddle(wg, base | (j << P));
       }
       ntt_reg_dif<3>(x + 8 * q);
 #pragma unroll
@@ -538,7 +544,13 @@ struct NttPass {
 // ---- which launches take the prefetching kernel (shared by the library and the emulation harness) ----
 // The slab shapes of a large forward transform, factors (if any) from a one-level table, and enough slabs that the shorter
 // grid still fills the chip.  (Forward passes only: the inverse instantiations need more VGPRs than four waves per SIMD leave.)
-inline bool ntt_pf_strided(const NttPassParams &p) { return p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333; }
+// the strided shapes: 4 (S 4, B 9), 7 (S 7, B 6), 0 = neither
+inline u32 ntt_pf_strided_s(const NttPassParams &p) {
+  if (p.L == 13 && p.S == 4 && p.B == 9 && p.nsteps == 3 && p.step_plan == 0x333) return 4;
+  if (p.L == 13 && p.S == 7 && p.B == 6 && p.nsteps == 2 && p.step_plan == 0x33) return 7;
+  return 0;
+}
+inline bool ntt_pf_strided(const NttPassParams &p) { return ntt_pf_strided_s(p) != 0; }
 inline bool ntt_pf_contiguous(const NttPassParams &p) {
   return p.L == 13 && p.S == 0 && p.B == 13 && p.nsteps == 4 && p.step_plan == 0x4333 && p.g_lo == 0 && p.scale_mode == 0 && p.canonical_in;
 }

@@ -177,7 +177,7 @@ struct NttHost {
         if (shift != 1 || zbits) {
           p.scale_mode = 2;
           p.sc = shift_table(shift, lg, zbits, false, 1, p.sc_lo_z_stride, p.sc_hi_z_stride, true);
-          if (computed_scale && p.sc.h == NTT_DIRECT && ntt_pf_strided(p)) p.sc_step = shift_step_table(shift, lg, zbits, g.g_lo + 5);
+          if (computed_scale && p.sc.h == NTT_DIRECT && ntt_pf_strided(p)) p.sc_step = shift_step_table(shift, lg, zbits, g.g_lo + 9 - g.S);  // a thread's elements are 512 >> S runs apart
         }
         wgs = 1u << (lg - g.L);
         nz = 1u << zbits;

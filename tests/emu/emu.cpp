@@ -27,21 +27,28 @@ struct EmuBackend {
       // k_ntt_pass_pf thread by thread: every phase for all threads before the next one (= the barriers of the kernel; the two
       // halves of the wave-local store of the contiguous pass are separated the same way)
       pf_launches++;
-      const bool strided = ntt_pf_strided(p);
+      const bool strided = ntt_pf_strided(p), s7 = ntt_pf_strided_s(p) == 7;
       const int fmode = !strided || !p.scale_mode ? 0 : (p.sc_step ? 2 : 1);
       std::vector<u64> regs((size_t)T * 16), twl(NttPass::PF_TW_WORDS_CONTIGUOUS);
-      for (u32 t = 0; t < T; t++) strided ? pass.pf_stage_twiddles<true>(twl.data(), t) : pass.pf_stage_twiddles<false>(twl.data(), t);
+      for (u32 t = 0; t < T; t++)
+        s7 ? pass.pf_stage_twiddles<true, 7>(twl.data(), t) : strided ? pass.pf_stage_twiddles<true>(twl.data(), t) : pass.pf_stage_twiddles<false>(twl.data(), t);
       for (u32 z = p.z_base; z < p.z_base + nz; z++)
         for (u32 c = 0; c < cols; c++)
           for (u32 w = 0; w < wgs; w++) {
             for (u32 t = 0; t < T; t++) pass.prefetch(t, T, w, c, z, &regs[16 * t]);
             for (u32 t = 0; t < T; t++) {
               if (!strided) pass.pf_first_step<false, 0>(lds.data(), t, w, z, &regs[16 * t], p.group_tw);
+              else if (s7 && fmode == 0) pass.pf_first_step<true, 0, 7>(lds.data(), t, w, z, &regs[16 * t], twl.data());
+              else if (s7 && fmode == 1) pass.pf_first_step<true, 1, 7>(lds.data(), t, w, z, &regs[16 * t], twl.data());
+              else if (s7) pass.pf_first_step<true, 2, 7>(lds.data(), t, w, z, &regs[16 * t], twl.data());
               else if (fmode == 0) pass.pf_first_step<true, 0>(lds.data(), t, w, z, &regs[16 * t], twl.data());
               else if (fmode == 1) pass.pf_first_step<true, 1>(lds.data(), t, w, z, &regs[16 * t], twl.data());
               else pass.pf_first_step<true, 2>(lds.data(), t, w, z, &regs[16 * t], twl.data());
             }
-            if (strided) {
+            if (s7) {
+              for (u32 t = 0; t < T; t++) pass.pf_last_strided_read<7>(lds.data(), t, &regs[16 * t]);
+              for (u32 t = 0; t < T; t++) pass.pf_last_strided_store<7>(t, w, c, z, &regs[16 * t]);
+            } else if (strided) {
               for (u32 t = 0; t < T; t++) pass.pf_mid_step<7>(lds.data(), t, 5, twl.data() + 512);
               for (u32 t = 0; t < T; t++) pass.pf_last_strided_read(lds.data(), t, &regs[16 * t]);
               for (u32 t = 0; t < T; t++) pass.pf_last_strided_store(t, w, c, z, &regs[16 * t]);

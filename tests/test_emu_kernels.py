@@ -136,6 +136,37 @@ def test_emu_coset_forward_headline_shape(oracle, emu, computed_scale):
     assert (out[3] == ref[perm]).all()
 
 
+@pytest.mark.parametrize("computed_scale", [False, True])
+def test_emu_lde_light_client_step_shape(oracle, emu, computed_scale):
+    """n = 2^19, the size of the light-client step: 6 strided + 13 contiguous bits.  The strided pass takes the two-step form of
+    the prefetching kernel (first step on the prefetched registers, then the last step straight from LDS to the stores); 8 columns
+    are the fewest for which the launches take it"""
+    lg, n = 19, 1 << 19
+    rng = np.random.default_rng(1900 + computed_scale)
+    x = rand_field(rng, (8, n), canonical=False)
+    lde = np.zeros((8, n * 8), dtype=np.uint64)
+    assert emu.emu_ntt_forward(vp(x), vp(lde), lg, 8, 7, 3 | (0x100 if computed_scale else 0)) == 2  # both passes
+    for c in (0, 6):
+        assert (lde[c:c + 1] == lde_leaf_order(oracle, x[c:c + 1] % np.uint64(P))).all()
+
+
+def test_emu_plain_and_coset_forward_light_client_step_shape(oracle, emu):
+    # the same strided shape without a factor (FMODE 0) and with the table factor of a single coset (FMODE 1 / 2)
+    lg, n = 19, 1 << 19
+    rng = np.random.default_rng(1919)
+    x = rand_field(rng, (64, n))
+    perm = bitrev_perm(lg)
+    for shift, flags in ((1, 0), (7, 0), (7, 0x100)):
+        out = np.zeros_like(x)
+        assert emu.emu_ntt_forward(vp(x), vp(out), lg, 64, shift, flags) == 2
+        ref = x[41].copy()
+        if shift == 1:
+            oracle.orc_fft(vp(ref), n)
+        else:
+            oracle.orc_coset_fft(vp(ref), n, shift)
+        assert (out[41] == ref[perm]).all()
+
+
 def test_emu_plain_forward_headline_shape(oracle, emu):
     # the same shapes without a coset scale (FMODE 0): 8 columns are the fewest for which the launch takes the prefetching form
     lg, n = 22, 1 << 22

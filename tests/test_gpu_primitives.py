@@ -90,6 +90,34 @@ def test_lde_headline_size_parity(gpu_ctx, oracle):
     assert (eight[6] == gpu_ctx.lde_batch(c[6:7], 3)[0]).all()
 
 
+def test_lde_light_client_step_size_parity(gpu_ctx, oracle):
+    """2^19 coefficients, the size of the light-client step: 6 strided + 13 contiguous bits; from 8 columns on the strided pass
+    takes the two-step form of the prefetching kernel (k_ntt_pass_pf<true, FMODE, 7>), below that the plain kernel: both against
+    the oracle, and the plain / coset transforms of lcp2_ntt_batch at 64 columns (the fewest that take it without cosets)"""
+    rng = np.random.default_rng(1919)
+    lg, n = 19, 1 << 19
+    c = rand_field(rng, (16, n), canonical=False)
+    cc = c % np.uint64(P)
+    two = gpu_ctx.lde_batch(c[0:2], 3)   # plain kernel
+    assert (two == lde_leaf_order(oracle, cc[0:2], 3)).all()
+    full = gpu_ctx.lde_batch(c, 3)       # prefetching kernel
+    assert (full[0:2] == two).all()
+    for k in (7, 15):
+        assert (full[k:k + 1] == lde_leaf_order(oracle, cc[k:k + 1], 3)).all()
+    x = rand_field(rng, (64, n), canonical=False)
+    xc = x % np.uint64(P)
+    for shift in (1, 7):
+        got = gpu_ctx.ntt_batch(x, shift=shift)
+        for k in (0, 37, 63):
+            want = xc[k].copy()
+            if shift == 1:
+                oracle.orc_fft(vp(want), n)
+            else:
+                oracle.orc_coset_fft(vp(want), n, shift)
+            assert (got[k] == want).all()
+        assert (gpu_ctx.ntt_batch(got, inverse=True, shift=shift) == xc).all()
+
+
 def test_ntt_large_roundtrip_and_linearity(gpu_ctx):
     # full-size property test (n = 2^22, the BASELINE degree): inverse(forward(x)) = x, and NTT(a+b) = NTT(a)+NTT(b)
     rng = np.random.default_rng(22)

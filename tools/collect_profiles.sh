@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/lc -o lc -- ./examples/lc_prover tmp_fixtures/u633.json tmp_fixtures/u634.json --repeat 2 > $out/lc.log 2>&1 && \
 ./tools/ubench/int_rates > $out/ubench.txt 2>&1 && \
 for rw in 1/2 2/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal.log || exit 1; done && \
+for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal.log || exit 1; done && \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/lcfetch -o lcfetch -- ./examples/lc_prover tmp_fixtures/u633.json tmp_fixtures/u634.json --extra-committees 6 --repeat 1 > $out/lcfetch.log 2>&1 && \
 python3 bench.py --force-sharded --no-cpu-baseline --no-real-gadgets > $out/bench_force_sharded.json 2> $out/bench_force_sharded.err && \
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "collect rc=$?"
