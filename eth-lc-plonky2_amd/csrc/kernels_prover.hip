@@ -380,12 +380,68 @@ struct QTerms {
     }
   }
 };
+// The same for the generated gates, with the limb table in LDS (the kernel stages it: 4 KB) and no branch on the challenge count
+// (with one challenge the second slot's limbs are zeros).  Why: a branch per constraint cuts an evaluator into hundreds of basic
+// blocks, across which hipcc sinks every recomposition chain to its use at the end of the function, with all its wires alive until
+// there; and in ONE block it hoists the ~600 scalar loads of a constant-space table to the top.  LDS reads are ordered by the
+// window barriers of the generated code (Q_WINDOW_BARRIER) like the wire loads are, so the generator's schedule survives.
+typedef const __attribute__((address_space(3))) u32 *lds_u32_ptr;
+struct QTermsLds {
+  u64 col[QUOTIENT_MAX_CH][6];
+  lds_u32_ptr limbs;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+#pragma unroll
+      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
+  }
+  // The column sums are plain integer additions: in one basic block hipcc reassociates the whole sum of a gate's ~100 terms into
+  // an order of its own, with every term (or its operands) alive until the end.  Passing the sums through an empty asm at the
+  // window boundaries of the generated code cuts the expression trees there.
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
+#pragma unroll
+      for (u32 l = 0; l < 6; l++) asm volatile("" : "+v"(col[c][l]));
+  }
+  template <u32 E>  // x * alpha^E
+  __device__ __forceinline__ void add(u64 x) {
+    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      lds_u32_ptr L = limbs + ((size_t)c * QUOTIENT_TERM_POWS + E) * 4;
+#pragma unroll
+      for (u32 l = 0; l < 3; l++) {
+        const u32 w = L[l];
+        col[c][l] += (u64)x0 * w;
+        col[c][3 + l] += (u64)x1 * w;
+      }
+    }
+  }
+  __device__ __forceinline__ void fold(u64 out[QUOTIENT_MAX_CH]) const {
+#pragma unroll
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      u64 v[3];
+#pragma unroll
+      for (u32 l = 0; l < 3; l++) {
+        const u64 lo = col[c][l] + (col[c][3 + l] << 32);
+        const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
+        v[l] = gl_reduce128(lo, hi);
+      }
+      out[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
+    }
+  }
+};
 // (an evaluator that uses the weighted terms never touches acc / step until finish_terms(): the compiler keeps only what is used)
 struct QEmit {
   u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
   u32 CH, emitted;
   bool weighted = false;  // acc is the finished combination sum_j alpha^j c_j (no rescaling by the caller)
   QTerms t;
+  QTermsLds tl;
+  __device__ __forceinline__ void begin_terms_lds() { tl.init(); }
+  __device__ __forceinline__ void finish_terms_lds() { tl.fold(acc); weighted = true; }
   __device__ __forceinline__ void begin_terms() { t.init(CH); }
   __device__ __forceinline__ void term(const QuotientArgs &a, u32 e, u64 x) { t.add(a, e, x); }  // x alpha^e; x any u64
   __device__ __forceinline__ void finish_terms() { t.fold(acc); weighted = true; }
@@ -552,10 +608,23 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
 #if defined(__HIP_DEVICE_COMPILE__)
 }  // namespace lcp2
 
+// window boundary of a generated gate: no memory access (wire loads, LDS limb reads) and no instruction moves across it
+#define Q_PIN(x) asm volatile("" : "+v"(x))
+#define Q_WINDOW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #include "generated_gates.hpp"
 namespace lcp2 {
 static_assert(Q_GENERATED_COUNT == QUOTIENT_GENERATED_GATES, "prover_kernels.hpp and generated_gates.hpp disagree");
 #endif
+
+// the alpha-limb table into LDS for the generated gates (every thread of the workgroup must call it: it ends in a barrier)
+constexpr u32 Q_LIMB_WORDS32 = QUOTIENT_MAX_CH * QUOTIENT_TERM_POWS * 4;
+__device__ __forceinline__ void q_stage_limbs(const QuotientArgs &a, u64 *lds, u32 T, u32 tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 *dst = (u32 *)(lds + a.limbs_lds_word);
+  for (u32 j = tid; j < Q_LIMB_WORDS32; j += T) dst[j] = konst(a.alpha_limbs)[j];
+  __syncthreads();
+#endif
+}
 
 // val[c] <- filter_g(point) * sum_i alpha_c^i constraint_{g,i}(point) for gate g at the point whose operands sit at index i.
 // NATIVE = 0 interprets the gate's program, LCP2_GATE_NATIVE_* runs the native evaluator of that plonky2 gate.
@@ -577,6 +646,7 @@ __device__ __forceinline__ void q_gate_value(const QuotientArgs &a, u32 g, const
   } else if (NATIVE == LCP2_GATE_NATIVE_BASE_SUM2) {
     q_base_sum2_native(a, i, G.num_constraints - 1, emit);
   } else if (NATIVE & 0x8000u) {
+    emit.tl.limbs = (lds_u32_ptr)(lds + a.limbs_lds_word);  // staged by the kernel (q_stage_limbs)
     q_generated<(NATIVE >> 8) & 0x7Fu>(a, i, emit);
   } else {
     // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
@@ -637,10 +707,11 @@ __device__ __forceinline__ GateDev q_load_gate(const QuotientArgs &a, u32 g) {
 // CHECK = true is the same evaluation over the rows of H (lcp2_prove's LCP2_E_UNSAT): on a row only its own gate has a
 // non-zero filter, so a wave skips a gate that none of its rows holds, and a non-zero value is a violated constraint.
 template <u32 NATIVE, bool CHECK>
-__global__ __launch_bounds__(QUOTIENT_THREADS, NATIVE == LCP2_GATE_NATIVE_POSEIDON ? 2 : 2) void k_q_gate(QuotientArgs a, u32 g, u32 accumulate, unsigned long long *flag) {
+__global__ __launch_bounds__(QUOTIENT_THREADS, NATIVE == LCP2_GATE_NATIVE_GENERATED(0) ? 4 : (NATIVE == LCP2_GATE_NATIVE_GENERATED(1) || NATIVE == LCP2_GATE_NATIVE_GENERATED(2)) ? 3 : 2) void k_q_gate(QuotientArgs a, u32 g, u32 accumulate, unsigned long long *flag) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i0 = (u64)blockIdx.x * T + tid;
+  if (NATIVE & 0x8000u) q_stage_limbs(a, lds, T, tid);
   if (!CHECK && i0 >= a.count) return;            // no barrier is used below
   const u64 i = i0 < a.count ? i0 : a.count - 1;  // CHECK: the tail re-checks the last row so that every lane votes
   const GateDev G = q_load_gate(a, g);
@@ -899,6 +970,7 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_native_check(QuotientAr
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i = (u64)blockIdx.x * T + tid;
+  if (NATIVE & 0x8000u) q_stage_limbs(a, lds, T, tid);
   if (i >= a.count) return;
   const GateDev G = q_load_gate(a, g);
   u64 r0[QUOTIENT_MAX_CH], r1[QUOTIENT_MAX_CH];
@@ -916,14 +988,17 @@ template <bool CHECK>
 void launch_gate(hipStream_t s, const QuotientArgs &a, const GateDev &G, u32 g, u32 accumulate, unsigned long long *flag) {
   const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
   const size_t stage = (size_t)QUOTIENT_STAGE * QUOTIENT_THREADS * sizeof(u64), interp = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  const size_t limbs = Q_LIMB_WORDS32 * 4;  // a generated gate: the LDS copy of the alpha-limb table, at word 0
+  QuotientArgs ag = a;
+  ag.limbs_lds_word = 0;
   switch (a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0) {
     case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_POSEIDON, CHECK>), grid, block, stage, s, a, g, accumulate, flag); break;
     case LCP2_GATE_NATIVE_ARITHMETIC: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_ARITHMETIC, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
     case LCP2_GATE_NATIVE_BASE_SUM2: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_BASE_SUM2, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(0), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(1), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(2), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(3), CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(0), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(1), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(2), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
+    case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(3), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
     default: hipLaunchKernelGGL((k_q_gate<0, CHECK>), grid, block, interp, s, a, g, accumulate, flag); break;
   }
 }
@@ -970,9 +1045,11 @@ void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<Gat
 void launch_gate_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
   launch_gates<true>(s, a, host_gates, flag);
 }
-void launch_native_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
+void launch_native_check(hipStream_t s, const QuotientArgs &a0, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
+  QuotientArgs a = a0;
   const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
-  const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  a.limbs_lds_word = (a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS;  // behind the interpreter's registers and staging slots
+  const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64) + Q_LIMB_WORDS32 * 4;
   for (u32 g = 0; g < host_gates.size(); g++)
     switch (host_gates[g].flags & LCP2_GATE_NATIVE_MASK) {
       case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_POSEIDON>), grid, block, lds, s, a, g, flag); break;

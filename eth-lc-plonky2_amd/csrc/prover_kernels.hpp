@@ -56,6 +56,7 @@ struct QuotientArgs {
   u32 use_native;          // 1: gates flagged LCP2_GATE_NATIVE_* run their native evaluator, 0: everything is interpreted
   const u64 *rc;           // Poseidon round constants (native PoseidonGate evaluator)
   const u64 *alpha_pow;    // [QUOTIENT_MAX_CH][QUOTIENT_ALPHA_POWS] alpha_c^e: weights of the permutation-term blocks
+  u32 limbs_lds_word;       // where in a kernel's dynamic LDS (in u64 words) the copy of alpha_limbs for the generated gates sits (set per launch)
   const u32 *alpha_limbs;  // [QUOTIENT_MAX_CH][QUOTIENT_TERM_POWS][4]: alpha_c^e cut into three 22-bit limbs (+ one word of padding): a
                            // generated gate adds constraint x limbs into six 64-bit column sums per challenge, one multiply-accumulate
                            // each and no reduction, and folds the columns once per point (kernels_prover.hip QTerms)
