@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""all_to_all_single over a ONE-rank RCCL group at growing message sizes, against the identity it should be:
+
+    python tools/rccl_a2a_probe.py          (on the GPU box; profiles/r03_rccl_a2a_probe.log)
+
+RCCL 2.26.6 (torch 2.10 + ROCm 7.0) copies a message up to 1 GiB correctly and only the first HALF of a larger one.  The sharded
+proof's row exchange (parallel.py TorchComm.all_to_all_tensor) therefore never hands RCCL a one-rank all-to-all (local copy) and
+cuts messages above 512 MiB per pair into pieces; a small known-answer self-check alone would not have caught this."""
 import os, sys, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
