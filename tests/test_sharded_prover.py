@@ -164,6 +164,29 @@ def _rerun(m, ctx, ranks, wires, pis, world):
 
 
 @pytest.mark.gpu
+def test_row_exchange_takes_a_non_canonical_witness(gpu_ctx):
+    """values in [p, 2^64) in the column shards: the rank's own iNTT canonicalises the coefficients, the row blocks are scanned by
+    lcp2_commit_wires_rows and K5 / the gate check continue from a canonical copy of the block: the same proof"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(7, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=23, small_values=True)
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    rng = np.random.default_rng(6)
+    P = np.uint64(m.GOLDILOCKS_P)
+    lifted = wires.copy()
+    idx = np.argwhere(lifted < np.uint64(2 ** 32 - 1))  # x + p < 2^64
+    for r, c in idx[rng.choice(len(idx), size=400, replace=False)]:
+        lifted[r, c] += P
+    assert (lifted >= P).sum() == 400
+    ranks = _run_lockstep(m, gpu_ctx, circ, lifted, pis, 4, True, True)
+    for r in ranks:
+        assert (r.proof == want).all()
+        r.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_row_exchange_reports_an_unsatisfied_witness_on_every_rank(gpu_ctx):
     """a violated gate constraint is found by the rank that holds the row and reaches the others through the verdict exchange;
     a broken copy constraint shows in the product of the block products, which every rank computes"""
