@@ -146,6 +146,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
         torch.cuda.synchronize()
         dist.barrier()
         comm.bytes_gathered = 0
+        comm.seconds = dict.fromkeys(comm.seconds, 0.0)
         t0 = time.perf_counter()
         proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True, row_exchange=rows)
         torch.cuda.synchronize()
@@ -165,6 +166,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
             "ms_per_proof": float(tt.item()) * 1e3, "world": world, "rccl_world_size": dist.get_world_size(), "proof_verified": ok,
             "all_gather_form": form, "witness_values_exchange": "all-to-all of row blocks" if rows else "all-gather of whole columns",
             "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
+            "exchange_ms_rank0_last_proof": {k: round(1e3 * v, 3) for k, v in comm.seconds.items()},  # wall time inside the synchronous collectives
             "exchange": ("RCCL all_gather_into_tensor (in place): witness coefficients, %s, %d planes of per-coset quotient interpolants; %s"
                          "all_reduce(SUM) of 3 caps and the proof array")
                         % ("Z / partial-product rows" if rows else "witness values", circ.params.num_challenges,

@@ -322,14 +322,19 @@ class TorchComm:
         self.staged = bool(int(os.environ.get("LCP2_SHARDED_STAGED", "0"))) if staged is None else bool(staged)
         self.bytes_gathered = 0  # received by this rank through all_gather_device / all_to_all_device (exchange accounting of the bench)
         self.row_exchange_ok = True  # self_check(): the all-to-all of the row exchange form reproduces a known answer
+        self.seconds = {"all_gather": 0.0, "all_to_all": 0.0, "all_reduce": 0.0}  # wall time inside the (synchronous) collectives
 
     def sum_host(self, arr):
+        import time
         import torch
+        t0 = time.perf_counter()
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy())
         if self.device is not None:
             t = t.to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # two's-complement wrap-around = uint64 addition
-        return t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
+        out = t.cpu().numpy().view(np.uint64).reshape(np.shape(arr))
+        self.seconds["all_reduce"] += time.perf_counter() - t0
+        return out
 
     def all_gather_tensor(self, out, rank):
         """all-gather on a 1-D tensor whose part r is out[r * k : (r + 1) * k].  In place over RCCL (it recognises the aliasing
@@ -357,13 +362,16 @@ class TorchComm:
         self.dist.all_gather_into_tensor(out, mine)
 
     def all_gather_device(self, ptr, total_words, words_per_rank):
+        import time
         import torch
         world = self.dist.get_world_size()
         assert total_words == words_per_rank * world
         self.ctx.sync()  # the library's stream has written this rank's part
+        t0 = time.perf_counter()
         out = torch.as_tensor(_DevicePtr(ptr, total_words), device=self.device)  # aliases the library's buffer: no staging copies
         self.all_gather_tensor(out, self.dist.get_rank())
         torch.cuda.synchronize(self.device)
+        self.seconds["all_gather"] += time.perf_counter() - t0
         self.bytes_gathered += 8 * words_per_rank * (world - 1)
 
     def all_to_all_tensor(self, recv, send):
@@ -391,13 +399,16 @@ class TorchComm:
 
     def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
         """all_to_all_tensor on two library buffers"""
+        import time
         import torch
         world = self.dist.get_world_size()
         self.ctx.sync()
+        t0 = time.perf_counter()
         send = torch.as_tensor(_DevicePtr(send_ptr, world * words_per_pair), device=self.device)
         recv = torch.as_tensor(_DevicePtr(recv_ptr, world * words_per_pair), device=self.device)
         self.all_to_all_tensor(recv, send)
         torch.cuda.synchronize(self.device)
+        self.seconds["all_to_all"] += time.perf_counter() - t0
         self.bytes_gathered += 8 * words_per_pair * (world - 1)
 
     def _check_all_to_all(self, words_per_pair):
