@@ -60,6 +60,7 @@ struct lcp2_circuit {
   // [row0(), row0() + rows()) only - rank r of `world` holds the r-th block of n / world rows - and runs the permutation
   // argument and the gate check on them
   bool rows_mode = false, cs_rows_ready = false;
+  int perm_phase = 0;  // row exchange form: 1 after lcp2_perm_zs_rows_begin, 2 after _finish (the order is enforced: _commit reads what they wrote)
   DevBuf cs_rows;   // the constants on this rank's rows, [num_constants][rows()]
   DevBuf zs_rows;   // exchange buffer of Z / partial products, [world][num_challenges * (1 + npp)][rows()]
   // a sharded circuit with at most 8 blocks interpolates the quotient coset by coset (each rank its own blocks, before the
@@ -536,6 +537,7 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
   if (rows_only && (!c->sharded() || !d_coeffs || wires_mem != LCP2_MEM_DEVICE || n < c->world()))
     return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_rows: needs a sharded circuit with at least one row per rank, device buffers");
   c->rows_mode = rows_only;
+  c->perm_phase = 0;
   const u64 *d_wires = wires_in;
   if (wires_mem == LCP2_MEM_HOST) {
     LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
@@ -1131,17 +1133,20 @@ extern "C" int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, c
   if (!c || !betas || !gammas || !block_products) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
   if (!c->rows_mode) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_begin: the wires were not committed with lcp2_commit_wires_rows");
+  c->perm_phase = 0;
   LCP2_TRY(perm_begin(c, (const u64 *)betas, (const u64 *)gammas));
   if (hipStreamSynchronize(c->ctx->stream) != hipSuccess) return c->ctx->fail(LCP2_E_HIP, "lcp2_perm_zs_rows_begin: stream synchronisation failed");
   const u32 CH = c->p.num_challenges;
   memset(block_products, 0, (size_t)c->world() * CH * 8);
   for (u32 k = 0; k < CH; k++) block_products[(size_t)c->rank() * CH + k] = gl_mul(c->perm_wrap[2 * k], c->perm_wrap[2 * k + 1]);
+  c->perm_phase = 1;
   return LCP2_OK;
 }
 extern "C" int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_products, uint64_t **device_ptr, size_t *words) {
   if (!c || !block_products || !device_ptr || !words) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_finish: no permutation argument in flight");
+  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES || c->perm_phase != 1)
+    return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_finish: lcp2_perm_zs_rows_begin has not run for this proof");
   const u32 CH = c->p.num_challenges;
   u64 prefix[QUOTIENT_MAX_CH];
   for (u32 k = 0; k < CH; k++) {
@@ -1155,6 +1160,7 @@ extern "C" int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_p
     if (all != 1) return c->ctx->fail(LCP2_E_UNSAT, "the witness violates a copy constraint (the permutation product does not return to 1)");
   }
   LCP2_TRY(perm_finish(c, prefix));
+  c->perm_phase = 2;
   *device_ptr = (uint64_t *)c->zs_rows.p;
   *words = (size_t)CH * (1 + npp_of(c->p)) << c->p.degree_bits;
   return LCP2_OK;
@@ -1162,7 +1168,9 @@ extern "C" int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_p
 extern "C" int lcp2_perm_zs_commit(lcp2_circuit *c, uint64_t *cap) {
   if (!c || !cap) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
-  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_commit: no permutation argument in flight");
+  if (!c->rows_mode || c->stage < lcp2_circuit::ST_WIRES || c->perm_phase != 2)
+    return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_commit: lcp2_perm_zs_rows_finish has not run for this proof");
+  c->perm_phase = 0;
   return perm_commit(c, (u64 *)cap);
 }
 extern "C" int lcp2_perm_zs(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *cap) {

@@ -396,6 +396,7 @@ int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, const uint6
  *                               [world][num_challenges * (1 + npp)][n / world] (*device_ptr, *words in total): an in-place
  *                               all-gather completes it.  LCP2_E_UNSAT (on every rank alike) if the product over all blocks is not 1.
  *   lcp2_perm_zs_commit         iNTT / LDE / Merkle tree of the completed buffer -> cap share
+ * (in this order, once each per proof: anything else is LCP2_E_INVALID)
  * lcp2_quotient_values then checks the gates on the rank's rows only: a caller must exchange the status (a rank that got
  * LCP2_E_UNSAT stops, and so must the others) before the next collective. */
 int lcp2_commit_wires_rows(lcp2_circuit *c, const uint64_t *wire_rows, const uint64_t *coeffs, uint64_t *cap);

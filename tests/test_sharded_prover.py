@@ -164,6 +164,57 @@ def _rerun(m, ctx, ranks, wires, pis, world):
 
 
 @pytest.mark.gpu
+def test_row_exchange_entry_points_refuse_misuse(gpu_ctx):
+    """lcp2_commit_wires_rows needs a sharded circuit; the rows_* calls need it to have run; the whole-column lcp2_perm_zs refuses
+    a handle that holds row blocks only; nothing is left half-done: the handle proves normally afterwards"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(6, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3)
+    n = 1 << 6
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    buf = gpu_ctx.buffer_alloc(params.num_wires * n)
+    gpu_ctx.buffer_write(buf, wires)
+    with pytest.raises(m.Lcp2Error):
+        single.commit_wires_rows(buf, buf)            # not a sharded circuit
+    with pytest.raises(m.Lcp2Error):
+        single.perm_zs_rows_begin(np.ones(2, np.uint64), np.ones(2, np.uint64), 1)
+    assert (single.prove(wires, pis) == want).all()
+    rank0 = m.parallel.ShardedProver(gpu_ctx, circ, 0, 1, None)  # one rank holding all 8 blocks
+    rank0.comm = type("C", (), {"sum_host": staticmethod(lambda a: a)})()
+    rank0.finish_build()
+    d = rank0.data
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_rows_begin(np.ones(2, np.uint64), np.ones(2, np.uint64), 1)   # no wires committed
+    coeffs = gpu_ctx.buffer_alloc(params.num_wires * n)
+    gpu_ctx.buffer_copy(coeffs, buf, params.num_wires * n)
+    gpu_ctx._check(gpu_ctx.lib.lcp2_ntt_batch(gpu_ctx.handle, __import__("ctypes").c_void_p(coeffs), params.num_wires, 6, 1, 1, m.MEM_DEVICE))
+    d.commit_wires_rows(buf, coeffs)
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs(np.ones(2, np.uint64), np.ones(2, np.uint64))                  # the handle holds row blocks: rows_* only
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_commit()                                                       # nothing to commit yet (no begin / finish)
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_rows_finish(np.ones(2, np.uint64))                             # no begin
+    betas, gammas = np.array([3, 5], np.uint64), np.array([7, 11], np.uint64)
+    products = d.perm_zs_rows_begin(betas, gammas, 1)
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_commit()                                                       # begin, but no finish
+    ptr, words = d.perm_zs_rows_finish(products)
+    assert words == 20 * n and ptr
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_rows_finish(products)                                          # twice
+    cap = d.perm_zs_commit()
+    assert (cap.reshape(-1, 4) != 0).any(axis=1).all()                           # one rank: the whole cap
+    with pytest.raises(m.Lcp2Error):
+        d.perm_zs_commit()                                                       # twice
+    gpu_ctx.buffer_free(buf)
+    gpu_ctx.buffer_free(coeffs)
+    rank0.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_row_exchange_takes_a_non_canonical_witness(gpu_ctx):
     """values in [p, 2^64) in the column shards: the rank's own iNTT canonicalises the coefficients, the row blocks are scanned by
     lcp2_commit_wires_rows and K5 / the gate check continue from a canonical copy of the block: the same proof"""
