@@ -538,6 +538,7 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
     return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_rows: needs a sharded circuit with at least one row per rank, device buffers");
   c->rows_mode = rows_only;
   c->perm_phase = 0;
+  c->fo.phase = 0;  // a new proof: an opening stage left half-way belongs to the previous one
   const u64 *d_wires = wires_in;
   if (wires_mem == LCP2_MEM_HOST) {
     LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * n * 8));
