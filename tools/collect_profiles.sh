@@ -6,6 +6,11 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=$1
 mkdir -p $out
+# the two light-client update files of the reference, out of the committed fixture (tests/golden/lc_updates.json)
+if [ ! -f tmp_fixtures/u634.json ]; then
+  mkdir -p tmp_fixtures
+  python3 -c "import json; d = json.load(open('tests/golden/lc_updates.json')); [json.dump(d[k], open('tmp_fixtures/u%s.json' % k, 'w')) for k in ('633', '634')]" || exit 1
+fi
 B="python3 bench.py --no-cpu-baseline --no-real-gadgets"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B --steps 2 --warmup 1 > $out/bench_under_rocprof.json 2> $out/kt.err && \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- $B --steps 1 --warmup 0 > $out/bench_under_pmc_fetch.json 2> $out/fetch.err && \
