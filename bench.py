@@ -387,18 +387,13 @@ def main():
     data.verify(proof, pis)  # raises if the GPU proof is not accepted
     sharded, rc = None, 0
     rccl_world = dist.get_world_size() if (world > 1 or a.force_sharded) else 1  # as the RCCL process group reports it
-    if (world > 1 or a.force_sharded) and not a.no_sharded and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
-        data.close()  # the replica's 92 GB workspace makes room for the sharded handle
-        torch.cuda.empty_cache()
-        try:
-            sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
-        except Exception as e:  # the replica line still goes out, but the run fails: configs[3] is a first-class result for N > 1
-            import traceback
-            traceback.print_exc()
-            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
-            rc = 3
+    reported = []  # the JSON line goes out exactly once: normally after the sharded side measurement, or from its watchdog
 
-    if rank == 0:
+    def report(sharded):
+        if rank != 0 or reported:
+            return
+        reported.append(True)
+        nonlocal w_dev
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt * 3600.0
         lh = prof_all["leaf_hash"]  # every k_hash_leaves launch of this process, as rocprofv3 --stats averages them
@@ -451,6 +446,32 @@ def main():
             if big:
                 out["config"]["real_gadget_circuit_2p22"] = big
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+    if (world > 1 or a.force_sharded) and not a.no_sharded and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
+        data.close()  # the replica's 92 GB workspace makes room for the sharded handle
+        torch.cuda.empty_cache()
+        # A collective that never completes (this exchange has not run over RCCL with more than one rank yet) must not take the
+        # replica result down with it: after LCP2_SHARDED_TIMEOUT_S the line goes out with the error and the rank exits non-zero.
+        import threading
+
+        def give_up():
+            report({"error": "the sharded proof did not finish within %s s (a collective hangs?)" % limit})
+            os._exit(3)
+        limit = float(os.environ.get("LCP2_SHARDED_TIMEOUT_S", "240"))
+        watchdog = threading.Timer(limit if rank == 0 else limit + 5.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
+        except Exception as e:  # the replica line still goes out, but the run fails: configs[3] is a first-class result for N > 1
+            import traceback
+            traceback.print_exc()
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+            rc = 3
+        finally:
+            watchdog.cancel()
+
+    report(sharded)
     if world > 1 or a.force_sharded:
         try:
             dist.destroy_process_group()
