@@ -29,6 +29,22 @@ MAX_REGS = 64
 GATE_EMIT_FORWARD = 1
 # "this program is plonky2's X gate": claims that lcp2_circuit_create checks against its native evaluators (include/lcp2.h)
 GATE_NATIVE_POSEIDON, GATE_NATIVE_ARITHMETIC, GATE_NATIVE_BASE_SUM2 = 0x100, 0x200, 0x300
+GATE_NATIVE_MASK = 0xFF00
+# Straight-line device evaluators generated offline from gate programs (tools/gen/gen_native_gates.cpp -> csrc/generated_gates_*.hpp):
+# the index of each program in the generated files, = the order of host/gates.cpp's SHA-256 gates followed by the order of
+# tools/gen/reference_gate_programs.txt (tests/test_generated_gates.py holds this table to the generated headers).  A GateSet claims
+# LCP2_GATE_NATIVE_GENERATED(k) for a gate of one of these names; lcp2_circuit_create checks the claim against the program, so a gate
+# of the same name with other parameters is refused at build(), never mis-proved (pass native=False for such a set).
+GENERATED_GATE_NAMES = ("ShaAddGate", "ShaRoundAGate", "ShaRoundEGate", "ShaScheduleGate",
+                        "ComparisonGate", "U32AddManyGate", "U32ArithmeticGate", "U32RangeCheckGate", "U32SubtractionGate", "CosetInterpolationGate",
+                        "PoseidonMdsGate", "ReducingExtensionGate", "ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate",
+                        "ExponentiationGate", "RandomAccessGate")
+GENERATED_GATE_INDEX = {name: k for k, name in enumerate(GENERATED_GATE_NAMES)}
+
+
+def gate_native_generated(k):
+    """LCP2_GATE_NATIVE_GENERATED(k) of include/lcp2.h"""
+    return 0x8000 | (k << 8)
 
 
 class Gate(ctypes.Structure):
@@ -271,8 +287,9 @@ def gate_poseidon(asm):
 class GateSet:
     """Sorted gate list + plonky2's greedy selector grouping (gates/selectors.rs::selector_polynomials)."""
 
-    def __init__(self, gates, max_degree=9):
+    def __init__(self, gates, max_degree=9, native=True):
         # gates: list of (name, degree, build_fn), already sorted by (degree, name) as plonky2 sorts its gate set
+        # native: claim the generated device evaluator for every gate that has one (GENERATED_GATE_INDEX); False = interpreted
         self.names = [g[0] for g in gates]
         self.degrees = [g[1] for g in gates]
         self.imm_table = ImmTable()
@@ -297,6 +314,8 @@ class GateSet:
             asm = GateAsm(self.imm_table)
             fn(asm)
             sel = next(i for i, (a, b) in enumerate(groups) if a <= gi < b)
+            if native and name in GENERATED_GATE_INDEX and not (asm.flags & GATE_NATIVE_MASK):
+                asm.flags |= gate_native_generated(GENERATED_GATE_INDEX[name])
             g = Gate(sel, gi, groups[sel][0], groups[sel][1], len(code) // 2, len(asm.words) // 2, asm.num_constraints, asm.flags)
             code += asm.words
             self.gates.append(g)
@@ -358,7 +377,7 @@ def standard_gateset():
     ])
 
 
-def synthetic_circuit(params, seed, npi=4, small_values=False):
+def synthetic_circuit(params, seed, npi=4, small_values=False, extra=None):
     """A satisfiable circuit of 2^degree_bits rows over plonky2's own gate set with real copy constraints, laid out the way
     circuit_builder.rs::build lays a circuit out:
       row 0        PublicInputGate: wires 0..4 carry public_inputs_hash
@@ -369,11 +388,15 @@ def synthetic_circuit(params, seed, npi=4, small_values=False):
       the rest     ArithmeticGate rows in pairs (the second row's multiplicands are the first row's outputs), the first one
                    reads the public inputs, one constant is fanned out to every 8th pair (a long permutation cycle)
       last rows    NoopGate padding
+    extra (optional): more gate types in the same circuit (u32_gates.ReferenceMix: the plonky2_u32 / comparison rows the reference's
+    SHA-256 and BigUint gadgets are made of).  An object with gateset() -> the GateSet of the whole circuit (it must contain the six
+    gates above), assign(gate_of_row, G, rng): gives rows that would have been ArithmeticGate rows to its own gates, and
+    fill(wires, gate_of_row, G, rng, link2): writes those rows' witness and their copy constraints.
     Returns (Circuit, wires [num_wires][n], public_inputs)."""
     rng = np.random.default_rng(seed)
     n = 1 << params.degree_bits
     Wn, NR = params.num_wires, params.num_routed_wires
-    gs = standard_gateset()
+    gs = extra.gateset() if extra is not None else standard_gateset()
     assert params.num_constants == gs.num_selectors + 2 and Wn >= pos.NUM_WIRES and NR >= 80
     G = {name: gs.index(name) for name in gs.names}
     rows = np.arange(n)
@@ -389,6 +412,8 @@ def synthetic_circuit(params, seed, npi=4, small_values=False):
     gate_of_row[prow] = G["PoseidonGate"]
     npad = min(4, n // 4)
     gate_of_row[n - npad:] = G["NoopGate"]
+    if extra is not None:
+        extra.assign(gate_of_row, G, rng)
     arith = np.nonzero(gate_of_row == G["ArithmeticGate"])[0]
     if arith.size % 2:
         gate_of_row[arith[-1]] = G["NoopGate"]
@@ -410,6 +435,9 @@ def synthetic_circuit(params, seed, npi=4, small_values=False):
         c = np.array([c[1] for c in cells])
         sig_row[c, r] = np.roll(r, -1)
         sig_col[c, r] = np.roll(c, -1)
+
+    if extra is not None:
+        extra.fill(wires, gate_of_row, G, rng, link2)
 
     # constants: wire_i = const_i on the ConstantGate rows; the last one provides the constant zero
     zero_row = int(crow[-1])

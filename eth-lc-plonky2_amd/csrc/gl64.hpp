@@ -240,6 +240,19 @@ LCP2_HD u64 gl_shl(u64 x) {
   }
 }
 
+// the lazy form of a short shift (any u64 in, any u64 congruent to x 2^S out)
+template <unsigned S>
+LCP2_HD u64 gl_shl_nc(u64 x) {
+  static_assert(S > 0 && S <= 32, "shift out of range");
+  return gl_reduce128_nc(x << S, x >> (64 - S));
+}
+// x * c for a 32-bit constant c: two 32 x 32 multiply-adds give the 96-bit product, one fold reduces it (x: any u64)
+LCP2_HD u64 gl_mul_u32_nc(u64 x, u32 c) {
+  const u64 p0 = (u64)(u32)x * c, p1 = (x >> 32) * c + (p0 >> 32);  // p1 < 2^64: (2^32 - 1)^2 + 2^32 - 1
+  return gl_reduce128_nc((p1 << 32) | (u32)p0, p1 >> 32);
+}
+LCP2_HD u64 gl_mul_u32(u64 x, u32 c) { return gl_canon(gl_mul_u32_nc(x, c)); }
+
 struct gl2 {
   u64 c0, c1;
 };

@@ -9,9 +9,7 @@
 //
 // Every kernel indexes the LDE matrices in their storage (= Merkle leaf) order, so all column reads are
 // coalesced 512-byte runs per wave; the only gathers are the two Z(g x) values per point in K6.
-#include "internal.hpp"
-#include "poseidon.hpp"
-#include "prover_kernels.hpp"
+#include "kernels_gates.hpp"
 
 namespace lcp2 {
 
@@ -203,42 +201,6 @@ void launch_perm_finalize(hipStream_t s, const PermArgs &a) {
   hipLaunchKernelGGL(k_perm_finalize, dim3((unsigned)((a.n + 255) / 256), a.num_challenges), dim3(256), 0, s, a);
 }
 
-// Read-only tables reached through an argument struct carry no `__restrict__`, so hipcc cannot prove a uniform load from them
-// invariant and emits a vector load + v_readfirstlane (a full memory round trip on the critical path of every interpreter
-// instruction).  Viewed through the constant address space the same load is an s_load from the scalar cache.  Only for data
-// that no kernel writes while this one runs (code, gate table, immediates, challenges: all uploaded before the launch).
-template <class T> using const_as = const T __attribute__((address_space(4))) *;
-template <class T> __device__ __forceinline__ const_as<T> konst(const T *p) { return (const_as<T>)(unsigned long long)p; }
-
-// ------------------------------------------------------------------ K6: quotient polynomial values on the LDE coset
-// Gate-program interpreter: registers live in LDS (reg r of thread t at lds[r * T + t]: conflict free), decode is
-// wave-uniform (scalar unit), operands come from the wires / constants LDE columns at this thread's point.
-__device__ __forceinline__ u64 q_operand(const QuotientArgs &a, u32 kind, u32 idx, const u64 *lds, u32 T, u32 tid, u64 i) {
-  switch (kind) {
-    case 0: return lds[idx * T + tid];
-    case 1: return a.wires[(u64)idx * a.stride + i];
-    case 2: return a.consts[(u64)(a.num_selectors + idx) * a.stride + i];
-    case 3: return konst(a.imm)[idx];
-    case 4: return konst(a.pis)[idx];
-    default: return lds[(a.num_regs + idx) * T + tid];  // QKIND_STAGE
-  }
-}
-
-// LDG: `cnt` column values of this thread's point into the staging slots.  All QUOTIENT_STAGE loads are issued back to back
-// (lanes past `cnt` repeat entry 0) before the first one is used: one HBM round trip for the whole group.
-__device__ __forceinline__ void q_stage(const QuotientArgs &a, u32 cnt, const_as<u32> lst, u64 *lds, u32 T, u32 tid, u64 i) {
-  u64 v[QUOTIENT_STAGE];
-#pragma unroll
-  for (u32 j = 0; j < QUOTIENT_STAGE; j++) {
-    const u32 e = lst[j < cnt ? j : 0];
-    const u64 *col = e < a.num_wires ? a.wires + (u64)e * a.stride : a.consts + (u64)(e - a.num_wires) * a.stride;
-    v[j] = col[i];
-  }
-#pragma unroll
-  for (u32 j = 0; j < QUOTIENT_STAGE; j++)
-    if (j < cnt) lds[(a.num_regs + j) * T + tid] = v[j];
-}
-
 // Host: the staged form of the programs.  Instructions are scanned in order; when one needs a WIRE / CONST operand that is not
 // in the current window, a new window opens: the distinct column operands of the instructions ahead are collected (in order of
 // first use) until QUOTIENT_STAGE of them are found, one LDG fetches them, and operands are rewritten to their slots.
@@ -294,169 +256,12 @@ void stage_gate_programs(const std::vector<uint32_t> &code, std::vector<GateDev>
   lists.resize(lists.size() + QUOTIENT_STAGE, 0);  // an LDG always reads entry 0 of its list: keep the tail readable
 }
 
-// Poseidon MDS layer on a window of 12 LDS registers (LCP2_OP_PMDS): the small-constant circulant on 32-bit halves with one
-// fold per element, exactly the layer of the hash kernels (poseidon.hpp), the 12 constants riding in the accumulators.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void q_pmds(u64 *lds, u32 T, u32 tid, u32 dst, u32 src, const_as<u64> add) {
-  const PosK k = pos_consts();
-  u32 lo[12], hi[12];
-  u64 rc[12];
-#pragma unroll
-  for (int j = 0; j < 12; j++) rc[j] = add[j];
-#pragma unroll
-  for (int j = 0; j < 12; j++) { const u64 v = lds[(src + j) * T + tid]; lo[j] = (u32)v; hi[j] = (u32)(v >> 32); }
-  pos_mds_h(lo, hi, rc, k);
-#pragma unroll
-  for (int j = 0; j < 12; j++) lds[(dst + j) * T + tid] = gl_canon(((u64)hi[j] << 32) | lo[j]);
-}
-__device__ __forceinline__ u64 q_sbox(u64 x) {
-  const PosK k = pos_consts();
-  u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-  pos_sbox_h(x0, x1, k);
-  return gl_canon(((u64)x1 << 32) | x0);
-}
-#else  // host pass of hipcc: declarations only
-__device__ void q_pmds(u64 *lds, u32 T, u32 tid, u32 dst, u32 src, const_as<u64> add);
-__device__ u64 q_sbox(u64 x);
-#endif
-
 // ---- native PoseidonGate (LCP2_GATE_NATIVE_POSEIDON): plonky2 gates/poseidon.rs::eval_unfiltered_base with the state in
 // VGPRs (32-bit halves, lazily reduced, exactly the permutation of the hash kernels) instead of LDS registers and one
 // interpreted instruction at a time.  Wires: input 0..12, output 12..24, swap 24, delta 25..29, S-box inputs of full rounds
 // 1..3 at 29 + 12 (r - 1) + i, of the partial rounds at 65 + r, of full rounds 4..7 at 87 + 12 r + i.  The constraints come out
 // first to last; acc is the Horner chain with 1 / alpha (rescaled by the caller), as for every EMIT_FORWARD gate.
 #if defined(__HIP_DEVICE_COMPILE__)
-// The running combination of a gate's constraints.  acc is kept LAZY (any u64 congruent to the value): a Horner step is a
-// 17-instruction multiply-reduce plus a 3-instruction add of the canonical constraint value, instead of 21 + 8 for canonical
-// arithmetic; whoever reads acc multiplies it with gl_mul, which accepts any u64 and returns a canonical value.
-// The constraint combination of a native gate, sum_j alpha^(e_j) c_j, without a multiply-REDUCE per constraint (a Horner chain
-// costs 17 + 3 instructions per constraint and challenge): alpha^e comes from a table as three 22-bit limbs, a constraint value
-// (any u64: it need not even be canonical) is two 32-bit halves, and each of the six half x limb products - below 2^54 - is one
-// v_mad_u64_u32 into a 64-bit column sum that 128 terms cannot overflow.  12 instructions per constraint and two challenges
-// instead of 40; the columns are folded (sum_l (col_l + col_(3+l) 2^32) 2^(22 l) mod p) once per point.
-struct QTerms {
-  u64 col[QUOTIENT_MAX_CH][6];
-  u32 CH;
-  __device__ __forceinline__ void init(u32 ch) {
-    CH = ch;
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-#pragma unroll
-      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
-  }
-  template <u32 E>  // x * alpha^E
-  __device__ __forceinline__ void add(const QuotientArgs &a, u64 x) {
-    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
-    add(a, E, x);
-  }
-  __device__ __forceinline__ void add(const QuotientArgs &a, u32 e /* wave-uniform, < QUOTIENT_TERM_POWS */, u64 x) {
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      if (c < CH) {
-        const_as<u32> L = konst(a.alpha_limbs) + ((size_t)c * QUOTIENT_TERM_POWS + e) * 4;
-#pragma unroll
-        for (u32 l = 0; l < 3; l++) {
-          const u32 w = L[l];
-          col[c][l] += (u64)x0 * w;
-          col[c][3 + l] += (u64)x1 * w;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void fold(u64 out[QUOTIENT_MAX_CH]) const {
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      if (c < CH) {
-        u64 v[3];
-#pragma unroll
-        for (u32 l = 0; l < 3; l++) {  // col_l + col_(3+l) 2^32 as a 128-bit value
-          const u64 lo = col[c][l] + (col[c][3 + l] << 32);
-          const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
-          v[l] = gl_reduce128(lo, hi);
-        }
-        out[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
-      }
-    }
-  }
-};
-// The same for the generated gates, with the limb table in LDS (the kernel stages it: 4 KB) and no branch on the challenge count
-// (with one challenge the second slot's limbs are zeros).  Why: a branch per constraint cuts an evaluator into hundreds of basic
-// blocks, across which hipcc sinks every recomposition chain to its use at the end of the function, with all its wires alive until
-// there; and in ONE block it hoists the ~600 scalar loads of a constant-space table to the top.  LDS reads are ordered by the
-// window barriers of the generated code (Q_WINDOW_BARRIER) like the wire loads are, so the generator's schedule survives.
-typedef const __attribute__((address_space(3))) u32 *lds_u32_ptr;
-struct QTermsLds {
-  u64 col[QUOTIENT_MAX_CH][6];
-  lds_u32_ptr limbs;
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-#pragma unroll
-      for (u32 l = 0; l < 6; l++) col[c][l] = 0;
-  }
-  // The column sums are plain integer additions: in one basic block hipcc reassociates the whole sum of a gate's ~100 terms into
-  // an order of its own, with every term (or its operands) alive until the end.  Passing the sums through an empty asm at the
-  // window boundaries of the generated code cuts the expression trees there.
-  __device__ __forceinline__ void pin() {
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-#pragma unroll
-      for (u32 l = 0; l < 6; l++) asm volatile("" : "+v"(col[c][l]));
-  }
-  template <u32 E>  // x * alpha^E
-  __device__ __forceinline__ void add(u64 x) {
-    static_assert(E < QUOTIENT_TERM_POWS, "too many constraints for the alpha power table");
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      lds_u32_ptr L = limbs + ((size_t)c * QUOTIENT_TERM_POWS + E) * 4;
-#pragma unroll
-      for (u32 l = 0; l < 3; l++) {
-        const u32 w = L[l];
-        col[c][l] += (u64)x0 * w;
-        col[c][3 + l] += (u64)x1 * w;
-      }
-    }
-  }
-  __device__ __forceinline__ void fold(u64 out[QUOTIENT_MAX_CH]) const {
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
-      u64 v[3];
-#pragma unroll
-      for (u32 l = 0; l < 3; l++) {
-        const u64 lo = col[c][l] + (col[c][3 + l] << 32);
-        const u64 hi = (col[c][3 + l] >> 32) + (lo < col[c][l] ? 1 : 0);
-        v[l] = gl_reduce128(lo, hi);
-      }
-      out[c] = gl_add(v[0], gl_add(gl_shl<22>(v[1]), gl_shl<44>(v[2])));
-    }
-  }
-};
-// (an evaluator that uses the weighted terms never touches acc / step until finish_terms(): the compiler keeps only what is used)
-struct QEmit {
-  u64 acc[QUOTIENT_MAX_CH], step[QUOTIENT_MAX_CH];
-  u32 CH, emitted;
-  bool weighted = false;  // acc is the finished combination sum_j alpha^j c_j (no rescaling by the caller)
-  QTerms t;
-  QTermsLds tl;
-  __device__ __forceinline__ void begin_terms_lds() { tl.init(); }
-  __device__ __forceinline__ void finish_terms_lds() { tl.fold(acc); weighted = true; }
-  __device__ __forceinline__ void begin_terms() { t.init(CH); }
-  __device__ __forceinline__ void term(const QuotientArgs &a, u32 e, u64 x) { t.add(a, e, x); }  // x alpha^e; x any u64
-  __device__ __forceinline__ void finish_terms() { t.fold(acc); weighted = true; }
-  __device__ __forceinline__ void operator()(u64 x) {  // forward gates: Horner with 1 / alpha (step = 0 encodes alpha = 0)
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) acc[c] = step[c] == 0 ? (emitted ? acc[c] : x) : gl_add_nc(gl_mul_nc(acc[c], step[c]), x);
-    emitted++;
-  }
-  __device__ __forceinline__ void horner(u64 x) {      // constraints listed last to first: Horner with alpha
-#pragma unroll
-    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-      if (c < CH) acc[c] = gl_add_nc(gl_mul_nc(acc[c], step[c]), x);
-  }
-};
 __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {
   const PosK k = pos_consts();
   const_as<u64> rc = konst(a.rc);
@@ -605,100 +410,22 @@ __device__ __forceinline__ void q_base_sum2_native(const QuotientArgs &a, u64 i,
 }
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__)
-}  // namespace lcp2
-
-// window boundary of a generated gate: no memory access (wire loads, LDS limb reads) and no instruction moves across it
-#define Q_PIN(x) asm volatile("" : "+v"(x))
-#define Q_WINDOW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#include "generated_gates.hpp"
-namespace lcp2 {
-static_assert(Q_GENERATED_COUNT == QUOTIENT_GENERATED_GATES, "prover_kernels.hpp and generated_gates.hpp disagree");
-#endif
-
-// the alpha-limb table into LDS for the generated gates (every thread of the workgroup must call it: it ends in a barrier)
-constexpr u32 Q_LIMB_WORDS32 = QUOTIENT_MAX_CH * QUOTIENT_TERM_POWS * 4;
-__device__ __forceinline__ void q_stage_limbs(const QuotientArgs &a, u64 *lds, u32 T, u32 tid) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  u32 *dst = (u32 *)(lds + a.limbs_lds_word);
-  for (u32 j = tid; j < Q_LIMB_WORDS32; j += T) dst[j] = konst(a.alpha_limbs)[j];
-  __syncthreads();
-#endif
-}
-
 // val[c] <- filter_g(point) * sum_i alpha_c^i constraint_{g,i}(point) for gate g at the point whose operands sit at index i.
-// NATIVE = 0 interprets the gate's program, LCP2_GATE_NATIVE_* runs the native evaluator of that plonky2 gate.
+// NATIVE = 0 interprets the gate's program, LCP2_GATE_NATIVE_* runs the native evaluator of that plonky2 gate (the generated
+// straight-line evaluators have kernels of their own: kernels_gates.hpp).
 template <u32 NATIVE>
 __device__ __forceinline__ void q_gate_value(const QuotientArgs &a, u32 g, const GateDev &G, u64 i, u64 *lds, u32 T, u32 tid, u64 val[QUOTIENT_MAX_CH]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const u32 CH = a.num_challenges;
-  const bool fwd = (G.flags & LCP2_GATE_EMIT_FORWARD) != 0;
-  // Horner step with alpha (constraints listed last to first) or with 1 / alpha (first to last; rescaled below).
-  // alpha = 0 in a forward gate (step = 0): the sum is the first constraint alone.
   QEmit emit;
-  emit.CH = CH; emit.emitted = 0;
-#pragma unroll
-  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) { emit.acc[c] = 0; emit.step[c] = c < CH ? (fwd ? konst(a.alpha_inv)[c] : konst(a.alphas)[c]) : 0; }
-  if (NATIVE == LCP2_GATE_NATIVE_POSEIDON) {
-    q_poseidon_native(a, i, lds, T, tid, emit);
-  } else if (NATIVE == LCP2_GATE_NATIVE_ARITHMETIC) {
-    q_arithmetic_native(a, i, G.num_constraints, emit);
-  } else if (NATIVE == LCP2_GATE_NATIVE_BASE_SUM2) {
-    q_base_sum2_native(a, i, G.num_constraints - 1, emit);
-  } else if (NATIVE & 0x8000u) {
-    emit.tl.limbs = (lds_u32_ptr)(lds + a.limbs_lds_word);  // staged by the kernel (q_stage_limbs)
-    q_generated<(NATIVE >> 8) & 0x7Fu>(a, i, emit);
-  } else {
-    // the instruction words are wave-uniform scalar loads: fetch one instruction ahead so that the scalar-cache round
-    // trip overlaps the arithmetic of the current instruction (the code array is padded by one instruction)
-    const_as<u64> code2 = konst((const u64 *)a.code);  // one instruction = two 32-bit words
-    u64 nxt = code2[G.code_offset];
-    for (u32 pc = G.code_offset; pc < G.code_offset + G.code_len; pc++) {
-      const u32 w0 = (u32)nxt, w1 = (u32)(nxt >> 32);
-      nxt = code2[pc + 1];
-      const u32 op = w0 & 0xF, dst = (w0 >> 8) & 0xFF, ka = (w0 >> 16) & 0xF, kb = (w0 >> 20) & 0xF, ia = w1 & 0xFFFF, ib = w1 >> 16;
-      if (op == QOP_LDG) { q_stage(a, dst, konst(a.stage_list) + w1, lds, T, tid, i); continue; }
-      if (op == LCP2_OP_PMDS) { q_pmds(lds, T, tid, dst, ia, konst(a.imm) + ib); continue; }
-      u64 x = q_operand(a, ka, ia, lds, T, tid, i);
-      if (op == LCP2_OP_EMIT || op == LCP2_OP_EMITBOOL) {
-        if (op == LCP2_OP_EMITBOOL) x = gl_sub(gl_mul(x, x), x);
-        if (fwd) emit(x); else emit.horner(x);
-        continue;
-      }
-      if (op == LCP2_OP_SBOX) { lds[dst * T + tid] = q_sbox(x); continue; }
-      u64 y = q_operand(a, kb, ib, lds, T, tid, i);
-      u64 r;
-      switch (op) {  // uniform across the wave: the code stream is the same for every point
-        case LCP2_OP_ADD: r = gl_add(x, y); break;
-        case LCP2_OP_SUB: r = gl_sub(x, y); break;
-        case LCP2_OP_MUL: r = gl_mul(x, y); break;
-        case LCP2_OP_XOR: { const u64 xy = gl_mul(x, y); r = gl_sub(gl_sub(gl_add(x, y), xy), xy); break; }
-        case LCP2_OP_DBLADD: r = gl_add(gl_add(x, x), y); break;
-        default: r = gl_add(lds[dst * T + tid], gl_mul(x, y)); break;  // LCP2_OP_MULADD
-      }
-      lds[dst * T + tid] = r;
-    }
-  }
-  const u64 s = a.consts[(u64)G.selector_index * a.stride + i];
-  u64 f = 1;
-  for (u32 j = G.group_start; j < G.group_end; j++)
-    if (j != G.selector_value) f = gl_mul(f, gl_sub((u64)j, s));
-  if (a.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
-#pragma unroll
-  for (u32 c = 0; c < QUOTIENT_MAX_CH; c++)
-    if (c < CH) {
-      const u64 sum = (fwd && !emit.weighted && emit.step[c] != 0) ? gl_mul(emit.acc[c], konst(a.gate_scale)[g * QUOTIENT_MAX_CH + c]) : emit.acc[c];
-      val[c] = gl_mul(f, sum);
-    }
+  q_emit_begin(a, G, emit);
+  if (NATIVE == LCP2_GATE_NATIVE_POSEIDON) q_poseidon_native(a, i, lds, T, tid, emit);
+  else if (NATIVE == LCP2_GATE_NATIVE_ARITHMETIC) q_arithmetic_native(a, i, G.num_constraints, emit);
+  else if (NATIVE == LCP2_GATE_NATIVE_BASE_SUM2) q_base_sum2_native(a, i, G.num_constraints - 1, emit);
+  else q_interpret(a, G, i, lds, T, tid, emit);
+  q_gate_finish(a, g, G, i, emit, val);
 #endif
 }
-__device__ __forceinline__ GateDev q_load_gate(const QuotientArgs &a, u32 g) {
-  GateDev G;  // field by field: an address-space-qualified struct has no implicit copy
-  const_as<u32> gw = konst((const u32 *)a.gates) + (size_t)g * (sizeof(GateDev) / 4);
-  G.selector_index = gw[0]; G.selector_value = gw[1]; G.group_start = gw[2]; G.group_end = gw[3];
-  G.code_offset = gw[4]; G.code_len = gw[5]; G.num_constraints = gw[6]; G.flags = gw[7];
-  return G;
-}
+
 
 // K6 is one launch per gate type plus the permutation pass: every kernel carries only the registers its gate needs (the native
 // PoseidonGate wants ~120 VGPRs, the permutation pass ~90, an interpreted gate ~80), so none drags the others' occupancy down,
@@ -707,11 +434,10 @@ __device__ __forceinline__ GateDev q_load_gate(const QuotientArgs &a, u32 g) {
 // CHECK = true is the same evaluation over the rows of H (lcp2_prove's LCP2_E_UNSAT): on a row only its own gate has a
 // non-zero filter, so a wave skips a gate that none of its rows holds, and a non-zero value is a violated constraint.
 template <u32 NATIVE, bool CHECK>
-__global__ __launch_bounds__(QUOTIENT_THREADS, NATIVE == LCP2_GATE_NATIVE_GENERATED(0) ? 4 : (NATIVE == LCP2_GATE_NATIVE_GENERATED(1) || NATIVE == LCP2_GATE_NATIVE_GENERATED(2)) ? 3 : 2) void k_q_gate(QuotientArgs a, u32 g, u32 accumulate, unsigned long long *flag) {
+__global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_q_gate(QuotientArgs a, u32 g, u32 accumulate, unsigned long long *flag) {
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i0 = (u64)blockIdx.x * T + tid;
-  if (NATIVE & 0x8000u) q_stage_limbs(a, lds, T, tid);
   if (!CHECK && i0 >= a.count) return;            // no barrier is used below
   const u64 i = i0 < a.count ? i0 : a.count - 1;  // CHECK: the tail re-checks the last row so that every lane votes
   const GateDev G = q_load_gate(a, g);
@@ -970,7 +696,6 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_native_check(QuotientAr
   extern __shared__ __attribute__((aligned(16))) u64 lds[];
   const u32 T = QUOTIENT_THREADS, tid = threadIdx.x;
   const u64 i = (u64)blockIdx.x * T + tid;
-  if (NATIVE & 0x8000u) q_stage_limbs(a, lds, T, tid);
   if (i >= a.count) return;
   const GateDev G = q_load_gate(a, g);
   u64 r0[QUOTIENT_MAX_CH], r1[QUOTIENT_MAX_CH];
@@ -983,22 +708,26 @@ __global__ __launch_bounds__(QUOTIENT_THREADS, 2) void k_native_check(QuotientAr
   if (bad) atomicMin(flag, (unsigned long long)i + 1);
 }
 
+// a generated evaluator lives in one of the kernels_gates_*.hip units: ask them in turn
+static bool launch_generated(hipStream_t s, const QuotientArgs &a, u32 k, u32 g, u32 accumulate, unsigned long long *flag, u32 mode) {
+  return launch_generated_sha(s, a, k, g, accumulate, flag, mode) || launch_generated_u32a(s, a, k, g, accumulate, flag, mode) ||
+         launch_generated_u32b(s, a, k, g, accumulate, flag, mode) || launch_generated_reca(s, a, k, g, accumulate, flag, mode) ||
+         launch_generated_recb(s, a, k, g, accumulate, flag, mode);
+}
 namespace {
 template <bool CHECK>
 void launch_gate(hipStream_t s, const QuotientArgs &a, const GateDev &G, u32 g, u32 accumulate, unsigned long long *flag) {
   const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
   const size_t stage = (size_t)QUOTIENT_STAGE * QUOTIENT_THREADS * sizeof(u64), interp = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
-  const size_t limbs = Q_LIMB_WORDS32 * 4;  // a generated gate: the LDS copy of the alpha-limb table, at word 0
-  QuotientArgs ag = a;
-  ag.limbs_lds_word = 0;
-  switch (a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0) {
+  const u32 kind = a.use_native ? (G.flags & LCP2_GATE_NATIVE_MASK) : 0;
+  if (kind & 0x8000u) {  // validate_programs has bounded the index
+    launch_generated(s, a, (kind >> 8) & 0x7Fu, g, accumulate, flag, CHECK ? GEN_ROW_CHECK : GEN_QUOTIENT);
+    return;
+  }
+  switch (kind) {
     case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_POSEIDON, CHECK>), grid, block, stage, s, a, g, accumulate, flag); break;
     case LCP2_GATE_NATIVE_ARITHMETIC: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_ARITHMETIC, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
     case LCP2_GATE_NATIVE_BASE_SUM2: hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_BASE_SUM2, CHECK>), grid, block, 0, s, a, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(0), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(1), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(2), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
-    case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_q_gate<LCP2_GATE_NATIVE_GENERATED(3), CHECK>), grid, block, limbs, s, ag, g, accumulate, flag); break;
     default: hipLaunchKernelGGL((k_q_gate<0, CHECK>), grid, block, interp, s, a, g, accumulate, flag); break;
   }
 }
@@ -1045,22 +774,19 @@ void launch_quotient(hipStream_t s, const QuotientArgs &a, const std::vector<Gat
 void launch_gate_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
   launch_gates<true>(s, a, host_gates, flag);
 }
-void launch_native_check(hipStream_t s, const QuotientArgs &a0, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
-  QuotientArgs a = a0;
+void launch_native_check(hipStream_t s, const QuotientArgs &a, const std::vector<GateDev> &host_gates, unsigned long long *flag) {
   const dim3 grid((unsigned)((a.count + QUOTIENT_THREADS - 1) / QUOTIENT_THREADS)), block(QUOTIENT_THREADS);
-  a.limbs_lds_word = (a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS;  // behind the interpreter's registers and staging slots
-  const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64) + Q_LIMB_WORDS32 * 4;
-  for (u32 g = 0; g < host_gates.size(); g++)
-    switch (host_gates[g].flags & LCP2_GATE_NATIVE_MASK) {
+  const size_t lds = (size_t)(a.num_regs + QUOTIENT_STAGE) * QUOTIENT_THREADS * sizeof(u64);
+  for (u32 g = 0; g < host_gates.size(); g++) {
+    const u32 kind = host_gates[g].flags & LCP2_GATE_NATIVE_MASK;
+    if (kind & 0x8000u) { launch_generated(s, a, (kind >> 8) & 0x7Fu, g, 0, flag, GEN_CLAIM_CHECK); continue; }
+    switch (kind) {
       case LCP2_GATE_NATIVE_POSEIDON: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_POSEIDON>), grid, block, lds, s, a, g, flag); break;
       case LCP2_GATE_NATIVE_ARITHMETIC: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_ARITHMETIC>), grid, block, lds, s, a, g, flag); break;
       case LCP2_GATE_NATIVE_BASE_SUM2: hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_BASE_SUM2>), grid, block, lds, s, a, g, flag); break;
-      case LCP2_GATE_NATIVE_GENERATED(0): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(0)>), grid, block, lds, s, a, g, flag); break;
-      case LCP2_GATE_NATIVE_GENERATED(1): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(1)>), grid, block, lds, s, a, g, flag); break;
-      case LCP2_GATE_NATIVE_GENERATED(2): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(2)>), grid, block, lds, s, a, g, flag); break;
-      case LCP2_GATE_NATIVE_GENERATED(3): hipLaunchKernelGGL((k_native_check<LCP2_GATE_NATIVE_GENERATED(3)>), grid, block, lds, s, a, g, flag); break;
       default: break;
     }
+  }
 }
 
 // ------------------------------------------------------------------ K7a: evaluate coefficient polynomials at an extension point

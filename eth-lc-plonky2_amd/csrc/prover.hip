@@ -177,7 +177,8 @@ static const char *validate_programs(const lcp2_circuit_desc *d) {
         if ((G.flags & LCP2_GATE_EMIT_FORWARD) || G.num_constraints < 2 || G.num_constraints > p.num_wires) return "LCP2_GATE_NATIVE_BASE_SUM2 needs num_limbs + 1 wires";
         break;
       default:
-        if (!(G.flags & 0x8000u) || ((G.flags >> 8) & 0x7Fu) >= QUOTIENT_GENERATED_GATES || (G.flags & LCP2_GATE_EMIT_FORWARD)) return "unknown native gate id";
+        // a generated evaluator weights constraint j with alpha^j whichever way the program lists them (the claim check decides)
+        if (!(G.flags & 0x8000u) || ((G.flags >> 8) & 0x7Fu) >= QUOTIENT_GENERATED_GATES || G.num_constraints > QUOTIENT_TERM_POWS) return "unknown native gate id";
         break;
     }
     size_t emits_seen = 0;

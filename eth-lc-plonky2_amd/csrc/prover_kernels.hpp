@@ -17,7 +17,7 @@ constexpr u32 QUOTIENT_MAX_CH = 2;
 constexpr u32 QUOTIENT_STAGE = 12;
 constexpr u32 QUOTIENT_ALPHA_POWS = 32; // >= CH + CH * PERM_MAX_CHUNKS + 1 exponents
 constexpr u32 QUOTIENT_TERM_POWS = 128; // alpha^e, e < 128, as 22-bit limbs: the constraint weights of the generated gates (at most 128 constraints)
-constexpr u32 QUOTIENT_GENERATED_GATES = 4;  // programs in csrc/generated_gates.hpp (static_assert-ed against the file)
+constexpr u32 QUOTIENT_GENERATED_GATES = 17; // programs in csrc/generated_gates*.hpp (static_assert-ed against the index file)
 constexpr u32 QOP_LDG = 10;      // w0 = 10 | count << 8, w1 = offset into stage_list
 constexpr u32 QKIND_STAGE = 5;   // operand = staging slot idx
 constexpr u32 EVAL_CHUNK = 4096;

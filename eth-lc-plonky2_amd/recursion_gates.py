@@ -2,7 +2,8 @@
 (plonky2 0.1.4 gates/arithmetic_extension.rs, multiplication_extension.rs, reducing.rs, reducing_extension.rs, random_access.rs,
 exponentiation.rs, poseidon_mds.rs;
 [RECALL] of the published source: wire layouts and the order of eval_unfiltered, D = 2, standard_recursion_config).  They run
-through the interpreter of K6 (no native evaluator is claimed) and through the host verifier like any other program; the
+on the device as generated straight-line evaluators (csrc/generated_gates_rec*.hpp; `native=False`: through the interpreter of K6) and through
+the host verifier like any other program; the
 recursive verifier of this repository (host/recursion.cpp) does not need them - it is made of ArithmeticGate operations - they
 are here so that a fork can hand a circuit that contains them to lcp2_circuit_create.
 
@@ -197,8 +198,9 @@ def gate_exponentiation(asm):
     asm.release(d)
 
 
-def recursion_gateset():
-    """sorted by (degree, name) as plonky2 sorts a gate set; two selector groups under max_degree 9"""
+def recursion_gateset(native=True):
+    """sorted by (degree, name) as plonky2 sorts a gate set; two selector groups under max_degree 9.  native: claim the generated
+    straight-line device evaluators (checked at build()); False: everything runs through the K6 interpreter"""
     return GateSet([
         ("NoopGate", 0, gate_noop),
         ("PoseidonMdsGate", 1, gate_poseidon_mds),
@@ -208,7 +210,7 @@ def recursion_gateset():
         ("MulExtensionGate", 3, gate_mul_extension),
         ("ExponentiationGate", 4, gate_exponentiation),
         ("RandomAccessGate", 5, gate_random_access),
-    ])
+    ], native=native)
 
 
 # ---------------------------------------------------------------- row generators (Python integers)
@@ -302,11 +304,11 @@ def row_exponentiation(rng, num_wires=135):
     return w
 
 
-def recursion_gates_circuit(params, seed):
+def recursion_gates_circuit(params, seed, native=True):
     """A provable circuit whose rows cycle through the seven gates (no copy constraints: identity permutation, no public inputs).
     Returns (Circuit, wires [num_wires][n], public_inputs = [])."""
     rng = np.random.default_rng(seed)
-    gs = recursion_gateset()
+    gs = recursion_gateset(native)
     n, Wn, NR = 1 << params.degree_bits, params.num_wires, params.num_routed_wires
     assert params.num_constants == gs.num_selectors + 2 and Wn >= 135 and NR >= 80
     kinds = ["ReducingGate", "ArithmeticExtensionGate", "MulExtensionGate", "ExponentiationGate", "RandomAccessGate", "ReducingExtensionGate",

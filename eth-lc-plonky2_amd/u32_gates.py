@@ -10,7 +10,8 @@ this container (un-vendored git dependencies, /root/reference/Cargo.lock:2388-23
 tests pin is that each program vanishes exactly on the rows its generator fills, has the constraint count of the gate's
 num_constraints() formula, and that a circuit of these gates proves on the GPU to the oracle's proof word for word.
 
-The programs run through the interpreter of K6 and the host verifier like any other program (no native evaluator is claimed).
+On the device the programs run as generated straight-line evaluators (tools/gen/gen_native_gates.cpp -> csrc/generated_gates_u32*.hpp; the
+claim is checked against the program at build()), with `native=False` through the interpreter of K6; the host verifier interprets them.
 """
 import numpy as np
 
@@ -320,8 +321,9 @@ def gate_coset_interpolation(asm):
     asm.release(*ev, *pr)
 
 
-def reference_gateset():
-    """sorted by (degree, name) as plonky2 sorts a gate set; three selector groups under max_degree 9"""
+def reference_gateset(native=True):
+    """sorted by (degree, name) as plonky2 sorts a gate set; three selector groups under max_degree 9.  native: claim the generated
+    straight-line device evaluators (checked at build()); False: everything runs through the K6 interpreter"""
     return GateSet([
         ("NoopGate", 0, gate_noop),
         ("ComparisonGate", 4, gate_comparison),
@@ -330,7 +332,7 @@ def reference_gateset():
         ("U32RangeCheckGate", 4, gate_u32_range_check),
         ("U32SubtractionGate", 4, gate_u32_subtraction),
         ("CosetInterpolationGate", 8, gate_coset_interpolation),
-    ])
+    ], native=native)
 
 
 # ---------------------------------------------------------------- row generators (Python integers)
@@ -476,11 +478,11 @@ ROW_GENERATORS = {
 }
 
 
-def reference_gates_circuit(params, seed):
+def reference_gates_circuit(params, seed, native=True):
     """A provable circuit whose rows cycle through the six gates (no copy constraints: identity permutation, no public inputs).
     Returns (Circuit, wires [num_wires][n], public_inputs = [])."""
     rng = np.random.default_rng(seed)
-    gs = reference_gateset()
+    gs = reference_gateset(native)
     n, Wn, NR = 1 << params.degree_bits, params.num_wires, params.num_routed_wires
     assert params.num_constants == gs.num_selectors + 2 and Wn >= 135 and NR >= 80
     kinds = list(ROW_GENERATORS)
@@ -496,3 +498,159 @@ def reference_gates_circuit(params, seed):
     consts = np.zeros((2, n), dtype=np.uint64)
     cs = np.concatenate([gs.selector_columns(gate_of_row), consts, sig])
     return Circuit(params, gs, cs, k_is, 0), wires, np.zeros(0, dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- a circuit with the gate mix of the reference's SHA-256 / BigUint gadgets
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _u32(rng, size):
+    return rng.integers(0, 1 << 32, size=size, dtype=np.uint64)
+
+
+def _digits_into(wires, first_wire, rows, value, count):
+    """two-bit limbs of `value` (uint64 array over `rows`), least significant first, on wires first_wire .. first_wire + count"""
+    for j in range(count):
+        wires[first_wire + j, rows] = (value >> np.uint64(2 * j)) & np.uint64(3)
+
+
+def fill_u32_arithmetic(wires, rows, rng):
+    """U32ArithmeticGate rows (row_u32_arithmetic, vectorised over `rows`)"""
+    for i in range(U32_ARITH_OPS):
+        m0, m1, addend = _u32(rng, rows.size), _u32(rng, rows.size), _u32(rng, rows.size)
+        out = m0 * m1 + addend          # < 2^64: (2^32 - 1)^2 + 2^32 - 1
+        lo, hi = out & _M32, out >> np.uint64(32)
+        for k, v in enumerate((m0, m1, addend, lo, hi)):
+            wires[6 * i + k, rows] = v
+        wires[6 * i + 5, rows] = gl.inv(_M32 - hi)   # hi <= 2^32 - 2: the inverse exists
+        _digits_into(wires, 6 * U32_ARITH_OPS + U32_ARITH_LIMBS * i, rows, out, U32_ARITH_LIMBS)
+
+
+def fill_u32_add_many(wires, rows, rng, first_addend=None):
+    """U32AddManyGate rows; first_addend[i] (optional): the value of addend_0 of operation i.  Returns the output_result of every operation."""
+    per, nl = ADD_MANY_ADDENDS + 3, ADD_MANY_RESULT_LIMBS + ADD_MANY_CARRY_LIMBS
+    results = []
+    for i in range(ADD_MANY_OPS):
+        addends = [_u32(rng, rows.size) for _ in range(ADD_MANY_ADDENDS)]
+        if first_addend is not None:
+            addends[0] = first_addend[i]
+        carry = rng.integers(0, 4, size=rows.size, dtype=np.uint64)
+        total = addends[0] + addends[1] + addends[2] + carry
+        res, out_carry = total & _M32, total >> np.uint64(32)
+        for k, v in enumerate(addends + [carry, res, out_carry]):
+            wires[per * i + k, rows] = v
+        _digits_into(wires, per * ADD_MANY_OPS + nl * i, rows, res, ADD_MANY_RESULT_LIMBS)
+        _digits_into(wires, per * ADD_MANY_OPS + nl * i + ADD_MANY_RESULT_LIMBS, rows, out_carry, ADD_MANY_CARRY_LIMBS)
+        results.append(res)
+    return results
+
+
+def fill_u32_subtraction(wires, rows, rng):
+    for i in range(SUB_OPS):
+        x, y = _u32(rng, rows.size), _u32(rng, rows.size)
+        borrow = rng.integers(0, 2, size=rows.size, dtype=np.uint64)
+        out_borrow = (x < y + borrow).astype(np.uint64)
+        res = (x + (out_borrow << np.uint64(32))) - y - borrow
+        for k, v in enumerate((x, y, borrow, res, out_borrow)):
+            wires[5 * i + k, rows] = v
+        _digits_into(wires, 5 * SUB_OPS + SUB_LIMBS * i, rows, res, SUB_LIMBS)
+
+
+def fill_u32_range_check(wires, rows, rng):
+    for i in range(RANGE_INPUTS):
+        x = _u32(rng, rows.size)
+        wires[i, rows] = x
+        _digits_into(wires, RANGE_INPUTS + RANGE_AUX * i, rows, x, RANGE_AUX)
+
+
+def fill_comparison(wires, rows, rng):
+    """ComparisonGate rows (row_comparison, vectorised): the chunk differences are in (-4, 4), so every intermediate is a small
+    signed integer; every eighth row compares equal inputs"""
+    nc = CMP_CHUNKS
+    a, b = _u32(rng, rows.size), _u32(rng, rows.size)
+    b[::8] = a[::8]
+    wires[0, rows], wires[1, rows] = a, b
+    inv_of = {d: pow(d % P, P - 2, P) for d in (-3, -2, -1, 1, 2, 3)}
+    inv_table = np.array([inv_of.get(d, 0) for d in range(-3, 4)], dtype=np.uint64)   # index diff + 3
+    so_far = np.zeros(rows.size, dtype=np.int64)
+
+    def field(v):  # small signed integers -> field elements
+        return np.where(v < 0, np.uint64(P) - (-v).astype(np.uint64), v.astype(np.uint64))
+
+    for i in range(nc):
+        fc = ((a >> np.uint64(2 * i)) & np.uint64(3)).astype(np.int64)
+        sc = ((b >> np.uint64(2 * i)) & np.uint64(3)).astype(np.int64)
+        diff = sc - fc
+        eq = (diff == 0).astype(np.int64)
+        wires[4 + i, rows], wires[4 + nc + i, rows] = fc.astype(np.uint64), sc.astype(np.uint64)
+        wires[4 + 2 * nc + i, rows] = inv_table[diff + 3]
+        wires[4 + 3 * nc + i, rows] = eq.astype(np.uint64)
+        inter = eq * so_far
+        wires[4 + 4 * nc + i, rows] = field(inter)
+        so_far = inter + (1 - eq) * diff
+    wires[3, rows] = field(so_far)
+    total = so_far + (1 << CMP_CHUNK_BITS)   # in [1, 7]
+    for i in range(CMP_CHUNK_BITS + 1):
+        wires[4 + 5 * nc + i, rows] = ((total >> i) & 1).astype(np.uint64)
+    wires[2, rows] = ((total >> CMP_CHUNK_BITS) & 1).astype(np.uint64)
+
+
+class ReferenceMix:
+    """`extra` of circuit.synthetic_circuit: the gate mix of a circuit built from the reference's own gadgets - plonky2_crypto's
+    two_to_one_sha256 (reference call sites src/merkle_tree_gadget.rs:37,57,77-79) lowers to U32AddMany rows, bit decompositions
+    (BaseSumGate<2>) and ArithmeticGate rows for the bitwise operations; the BigUint slot logic (src/targets.rs:184-235,304-332)
+    to U32Arithmetic / U32Subtraction / U32RangeCheck / Comparison rows; build() adds the PoseidonGate rows of the public-input hash.
+    Of every 16 rows: 6 U32AddMany (in pairs: the second row's first addends are copy-constrained to the first row's results),
+    2 U32Arithmetic, 1 U32RangeCheck, 1 U32Subtraction, 1 Comparison, 1 BaseSum, 4 Arithmetic.  The gate set sorts as plonky2 sorts
+    it (degree, name): three selector groups, 5 constant columns."""
+    PATTERN = {0: "U32AddManyGate", 1: "U32AddManyGate", 2: "U32AddManyGate", 3: "U32AddManyGate", 4: "U32AddManyGate", 6: "U32AddManyGate",
+               7: "U32ArithmeticGate", 8: "U32ArithmeticGate", 9: "U32RangeCheckGate", 10: "U32SubtractionGate", 11: "ComparisonGate"}
+
+    def __init__(self, native=True):
+        self.native = native
+
+    def gateset(self):
+        from .circuit import (BASE_SUM_LIMBS, gate_arithmetic, gate_base_sum, gate_constant, gate_poseidon, gate_public_input)
+        return GateSet([
+            ("NoopGate", 0, gate_noop),
+            ("ConstantGate", 1, gate_constant),
+            ("PublicInputGate", 1, gate_public_input),
+            ("BaseSumGate", 2, gate_base_sum(BASE_SUM_LIMBS)),
+            ("ArithmeticGate", 3, gate_arithmetic),
+            ("ComparisonGate", 4, gate_comparison),
+            ("U32AddManyGate", 4, gate_u32_add_many),
+            ("U32ArithmeticGate", 4, gate_u32_arithmetic),
+            ("U32RangeCheckGate", 4, gate_u32_range_check),
+            ("U32SubtractionGate", 4, gate_u32_subtraction),
+            ("PoseidonGate", 7, gate_poseidon),
+        ], native=self.native)
+
+    def assign(self, gate_of_row, G, rng):
+        rows = np.arange(gate_of_row.size)
+        free = gate_of_row == G["ArithmeticGate"]
+        for r, name in self.PATTERN.items():
+            gate_of_row[free & (rows % 16 == r)] = G[name]
+
+    def fill(self, wires, gate_of_row, G, rng, link2):
+        am = np.nonzero(gate_of_row == G["U32AddManyGate"])[0]
+        if am.size % 2:   # the row without a partner stands alone
+            fill_u32_add_many(wires, am[-1:], rng)
+            am = am[:-1]
+        first, second = am[0::2], am[1::2]
+        if first.size:
+            res = fill_u32_add_many(wires, first, rng)
+            fill_u32_add_many(wires, second, rng, first_addend=res)
+            per = ADD_MANY_ADDENDS + 3
+            for i in range(ADD_MANY_OPS):
+                link2(second, per * i, first, per * i + ADD_MANY_ADDENDS + 1)
+        for name, fn in (("U32ArithmeticGate", fill_u32_arithmetic), ("U32RangeCheckGate", fill_u32_range_check),
+                         ("U32SubtractionGate", fill_u32_subtraction), ("ComparisonGate", fill_comparison)):
+            rows = np.nonzero(gate_of_row == G[name])[0]
+            if rows.size:
+                fn(wires, rows, rng)
+
+
+def reference_mix_circuit(params, seed, native=True, small_values=False):
+    """circuit.synthetic_circuit with the reference's gate mix (ReferenceMix): (Circuit, wires, public_inputs); params.num_constants = 5"""
+    from .circuit import synthetic_circuit
+    return synthetic_circuit(params, seed, small_values=small_values, extra=ReferenceMix(native))

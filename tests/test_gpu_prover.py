@@ -430,14 +430,16 @@ def test_nonstandard_params_equal_oracle(gpu_ctx, oracle, name, degree_bits, kw)
     oc.close()
 
 
-@pytest.mark.parametrize("degree_bits", [5, 8, 11])
-def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
+@pytest.mark.parametrize("degree_bits,native", [(5, True), (8, True), (8, False), (11, True)])
+def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits, native):
     """a circuit of plonky2's recursion gates (recursion_gates.py: extension arithmetic, the reducing gates, RandomAccessGate,
-    ExponentiationGate, PoseidonMdsGate, all interpreted by K6): the GPU proof equals the oracle's word for word and verifies"""
+    ExponentiationGate, PoseidonMdsGate; native: the generated straight-line evaluators, whose claims build() checks against the
+    programs, else interpreted by K6): the GPU proof equals the oracle's word for word and verifies"""
     import eth_lc_plonky2_amd as m
     from eth_lc_plonky2_amd import recursion_gates as rg
     params = m.standard_params(degree_bits, 4)
-    circ, wires, pis = rg.recursion_gates_circuit(params, seed=40 + degree_bits)
+    circ, wires, pis = rg.recursion_gates_circuit(params, seed=40 + degree_bits, native=native)
+    assert all(bool(g.flags & 0x8000) == (native and g.num_constraints > 0) for g in circ.gateset.gates)
     oc = oracle_lib.OracleCircuit(oracle, circ)
     want = oc.prove(wires, pis)
     data = m.CircuitData.build(gpu_ctx, circ)
@@ -453,16 +455,16 @@ def test_recursion_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
     oc.close()
 
 
-@pytest.mark.parametrize("degree_bits", [6, 9])
-def test_reference_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
+@pytest.mark.parametrize("degree_bits,native", [(6, True), (9, True), (9, False)])
+def test_reference_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits, native):
     """a circuit of the gates the reference's own circuit is made of (u32_gates.py: plonky2_u32's U32 arithmetic / add-many /
     subtraction / range-check gates, ComparisonGate, plonky2's CosetInterpolationGate - degree-4 and degree-8 constraints, three
-    selector groups - all interpreted by K6): the GPU proof equals the oracle's word for word and verifies; a broken row is
-    LCP2_E_UNSAT"""
+    selector groups; native: generated straight-line evaluators, else interpreted by K6): the GPU proof equals the oracle's word
+    for word and verifies; a broken row is LCP2_E_UNSAT"""
     import eth_lc_plonky2_amd as m
     from eth_lc_plonky2_amd import u32_gates as ug
     params = m.standard_params(degree_bits, 5)
-    circ, wires, pis = ug.reference_gates_circuit(params, seed=60 + degree_bits)
+    circ, wires, pis = ug.reference_gates_circuit(params, seed=60 + degree_bits, native=native)
     oc = oracle_lib.OracleCircuit(oracle, circ)
     want = oc.prove(wires, pis)
     data = m.CircuitData.build(gpu_ctx, circ)
@@ -479,3 +481,73 @@ def test_reference_gate_programs_prove_on_the_gpu(gpu_ctx, oracle, degree_bits):
         assert e.value.status == -5, kind  # LCP2_E_UNSAT
     data.close()
     oc.close()
+
+
+@pytest.mark.parametrize("degree_bits", [10, 14])
+def test_reference_gate_mix_proof_equals_oracle(gpu_ctx, oracle, degree_bits):
+    """The gate mix of a circuit built from the reference's own gadgets (u32_gates.ReferenceMix: U32AddMany / U32Arithmetic /
+    U32RangeCheck / U32Subtraction / Comparison rows next to BaseSum, Arithmetic, Constant, PublicInput and PoseidonGate rows, real
+    copy constraints, the public inputs hashed in-circuit; 11 gate types in three selector groups) - what `bench.py` times at 2^22 rows
+    as config.reference_gate_set_2p22.  With the generated native evaluators and interpreted the GPU gives the same proof, and it is
+    the oracle's proof word for word; both verifiers accept it; a broken u32 row is LCP2_E_UNSAT."""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import u32_gates as ug
+    params = m.standard_params(degree_bits, 5)
+    circ, wires, pis = ug.reference_mix_circuit(params, seed=300 + degree_bits)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    assert oc.check_witness(wires, pis)[0] == 0
+    want = oc.prove(wires, pis)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    d_gpu, cap_gpu = data.digest()
+    d_orc, cap_orc = oc.digest()
+    assert (cap_gpu == cap_orc).all() and (d_gpu == d_orc).all()
+    got = data.prove(wires, pis)
+    assert _first_mismatch(m, params, got, want) is None, _first_mismatch(m, params, got, want)
+    data.verify(got, pis)
+    assert oc.verify(got, pis) == 0
+    gs = circ.gateset
+    rows = {name: int(np.nonzero(circ.constants_sigmas[gs.gates[gs.index(name)].selector_index] == np.uint64(gs.index(name)))[0][3])
+            for name in ("U32AddManyGate", "U32ArithmeticGate", "U32RangeCheckGate", "U32SubtractionGate", "ComparisonGate")}
+    for name, wire in (("U32AddManyGate", 4), ("U32ArithmeticGate", 3), ("U32RangeCheckGate", 7 + 16 * 3 + 2), ("U32SubtractionGate", 3), ("ComparisonGate", 2)):
+        w2 = wires.copy()
+        w2[wire, rows[name]] ^= np.uint64(1)
+        with pytest.raises(m.Lcp2Error) as e:
+            data.prove(w2, pis)
+        assert e.value.status == -5, name  # LCP2_E_UNSAT
+    data.close()
+    circ_i, wires_i, pis_i = ug.reference_mix_circuit(params, seed=300 + degree_bits, native=False)
+    assert (wires_i == wires).all() and not any(g.flags & 0x8000 for g in circ_i.gateset.gates)
+    data = m.CircuitData.build(gpu_ctx, circ_i)
+    assert (data.prove(wires_i, pis_i) == want).all(), "the interpreted form gives another proof"
+    data.close()
+    oc.close()
+
+
+def test_generated_gate_claim_is_checked_at_build(gpu_ctx):
+    """LCP2_GATE_NATIVE_GENERATED(k) is a claim like the plonky2-gate ones: a program that is not program k of csrc/generated_gates*.hpp
+    (one immediate changed, one wire index changed, or the claim of another gate) is refused by build(); unclaimed it is interpreted."""
+    import eth_lc_plonky2_amd as m
+    from eth_lc_plonky2_amd import u32_gates as ug
+    params = m.standard_params(6, 5)
+    circ, wires, pis = ug.reference_gates_circuit(params, seed=3)
+    gs = circ.gateset
+    m.CircuitData.build(gpu_ctx, circ).close()
+    g = gs.gates[gs.index("U32SubtractionGate")]
+    pc = g.code_offset + 3     # SUB t, t, borrow (wire 2 of operation 0)
+    assert gs.code[2 * pc] & 0xF == m.circuit.OP_SUB
+    gs.code[2 * pc + 1] ^= np.uint32(1 << 16)
+    with pytest.raises(m.Lcp2Error) as e:
+        m.CircuitData.build(gpu_ctx, circ)
+    assert e.value.status == -1 and "NATIVE" in str(e.value)
+    gs.code[2 * pc + 1] ^= np.uint32(1 << 16)
+    claim = g.flags
+    g.flags = (g.flags & ~m.circuit.GATE_NATIVE_MASK) | m.circuit.gate_native_generated(m.circuit.GENERATED_GATE_INDEX["U32RangeCheckGate"])
+    with pytest.raises(m.Lcp2Error):
+        m.CircuitData.build(gpu_ctx, circ)
+    g.flags = claim & ~m.circuit.GATE_NATIVE_MASK   # unclaimed: interpreted
+    m.CircuitData.build(gpu_ctx, circ).close()
+    g.flags = claim
+    k = int(np.nonzero(gs.imm == np.uint64(1 << 32))[0][0])
+    gs.imm[k] ^= np.uint64(2)
+    with pytest.raises(m.Lcp2Error):
+        m.CircuitData.build(gpu_ctx, circ)
