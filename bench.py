@@ -3,59 +3,69 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one `data.prove(witness)` (the region the reference times, eth-lc-plonky2/src/main.rs:229-232)
-over the BASELINE workload configs[2]: a light-client-sized circuit, n = 2^22 rows, 135 wires (80 routed),
-standard_recursion_config (rate 1/8, cap height 4, 2 challenges, quotient degree factor 8, 5 arity-16 FRI
-layers, 16 PoW bits, 28 queries).  The circuit is the synthetic satisfiable one of
-eth-lc-plonky2_amd/circuit.py over plonky2's own gate set (NoopGate, ConstantGate, PublicInputGate,
-BaseSumGate<2>, ArithmeticGate, PoseidonGate as gate programs; the public inputs hashed in-circuit as
-circuit_builder.rs::build does; real copy constraints); the witness is resident in HBM when the timed region
-starts and the proof produced in the last step is checked by the verifier.  Side fields carry the same
-prover on circuits built from the reference's own gadgets by the C++ host layer, device-side witness
-generation included: `config.sync_committee_ssz` (BASELINE configs[1]: the SyncCommitteeSSZ gadget alone),
-`config.real_lc_step` (updates 633 -> 634, 2^19 rows in the own SHA-256 layout), `config.real_lc_step_recursive`
-(the same with the recursive verification of an inner proof that has the BLS proof's public inputs) and
-`config.real_gadget_circuit_2p22` (the step plus six more SyncCommitteeSSZ gadgets: 2.24 M gates, 2^22 rows).
+A step = one `data.prove(pw)` of eth-lc-plonky2/src/main.rs:229-232 - the region the reference times, witness generation
+(`generate_partial_witness`) INSIDE it - on a circuit built from the reference's own gadgets by the C++ host layer
+(eth-lc-plonky2_amd/host, through host/lc_capi.h in this process): the light-client step for the reference's update pair 633 -> 634
+(add_virtual_proof_target, src/targets.rs:391-683; 16 public inputs cur_state / new_state) plus six more SyncCommitteeSSZ gadgets,
+7 207 two_to_one_sha256, 2 240 740 gates = 2^22 rows of 135 wires under standard_recursion_config - the reference's scale
+(README.md:71, "~2.98 M gates"; this library's SHA-256 layout needs 310 rows per hash where plonky2_crypto needs ~2 800, so
+the bare step is 2^19 rows) made of real gadgets.  The recursive BLS verifier is stubbed (BASELINE configs[2]).  The PartialWitness
+is a host object (a few thousand values); the SHA-256 rows are generated on the device (K10), the proof is verified and its public
+inputs compared with the natively computed contract states.  `data`: the two real mainnet updates of the reference repository
+(tests/golden/lc_updates.json), nothing synthetic.
+
+Side fields (`config.*`, N = 1 only, each with the HIP-event time per kernel family and a roofline block of its own):
+  real_lc_step / sync_committee_ssz / real_lc_step_recursive   the step at its true size (2^19 rows), BASELINE configs[1] (the
+      SyncCommitteeSSZ gadget alone), and the step with the recursive verification of a stand-in inner proof;
+  synthetic_plonky2_gate_set_2p22     the headline of rounds 1-3: a synthetic satisfiable circuit over plonky2's own gate set
+      (Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon) at 2^22 rows, witness resident in HBM (lcp2_prove alone);
+  reference_gate_set_2p22             the same with the reference's real gate set (plonky2_u32 U32AddMany / U32Arithmetic / U32RangeCheck /
+      U32Subtraction, ComparisonGate next to BaseSum / Arithmetic / Poseidon) on generated native evaluators: quotient time, VGPRs per
+      gate kernel, K6 FETCH_SIZE ratio of the committed PMC pass;
+  host_witness_2p22                   lcp2_prove with the witness in HOST memory (what a fork with its own generators hands over):
+      pinned, double-buffered upload of witness i+1 on a second stream while proof i runs.
 
 `--gpus N` without WORLD_SIZE in the environment: this process only LAUNCHES the N ranks (child processes of this script with
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; it never imports torch or touches HIP), relays rank 0's line and passes a failing
 rank's exit code on.  With WORLD_SIZE set (torch.distributed.run) the process is a rank.
 
-N > 1: one rank per GPU, every rank proves its own witness of the same circuit (BASELINE configs[4],
-independent light-client updates: "replicas", no data-path collective) -> weak scaling; the only
-collectives are the timing barrier and the max-reduce of the elapsed time.  After that timed region the same
-ranks prove ONE proof together, sharded by LDE coset with the witness arriving column-sharded (BASELINE
-configs[3]; eth-lc-plonky2_amd/parallel.py::ShardedProver over RCCL: all-gathers of the witness, its
-coefficients and the quotient planes, sum all-reduces of caps and proof shares); its wall time is reported
-beside the headline value as `config.sharded_proof` (`value` stays the replica throughput; a failure of the sharded proof is a
-non-zero exit code).
+N > 1: one rank per GPU, every rank proves the same circuit for its own update (BASELINE configs[4], independent light-client
+updates: "replicas", no data-path collective) -> weak scaling; the only collectives are the timing barrier and the max-reduce of the
+elapsed time.  After that timed region the ranks (a) prove a batch of 32 updates data-parallel through batch.prove_batch (configs[4]
+as worded: 32 / N per rank, proofs gathered on rank 0) and (b) prove ONE proof together, sharded by LDE coset (BASELINE configs[3];
+eth-lc-plonky2_amd/parallel.py::ShardedProver over RCCL) - reported as `config.batch_of_32` and `config.sharded_proof`; `value` stays
+the replica throughput; a failure of the sharded proof is a non-zero exit code.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing, K4a):
-algorithmic bytes per launch / HIP-event time per launch measured inside this run.  `cpu_baseline` is the
-oracle (oracle/, kind "port") timed on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing, K4a, integer-VALU bound):
+algorithmic bytes per launch / HIP-event time per launch measured inside this run.  `cpu_baseline` is the oracle (oracle/, kind
+"port") timed on a bounded sample; the GPU proves the same sample and the two proofs must be equal word for word.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a full-rate wave64 VALU instruction issues in 2 cycles, 2.4 GHz -> 78.6 T lane-instructions/s
 VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9
 CLOCK_HZ = 2.4e9
 CENSUS = os.path.join(ROOT, "profiles", "r03_poseidon_census.json")  # tools/poseidon_census.py: VALU instructions per permutation as compiled
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of the bench (tools/collect_profiles.sh)
+REFERENCE_MIX_PMC = os.path.join(ROOT, "profiles", "r04_reference_mix_k6.json")  # tools/k6_profile_summary.py: K6 kernel times and FETCH_SIZE of the reference gate set
 
 
 def valu_roofline(perms_per_s):
     """Poseidon is integer-VALU bound.  One denominator: the full-rate VALU peak of the guide (every wave64 instruction at 2 cycles,
     78.6 T lane-instructions/s).  No stream of 64-bit integer multiplies can reach it on this ISA - v_mad_u64_u32 and the carry ops
     issue at 4.2-4.4 cycles alone (profiles/r02_ubench_int_rates.txt) - so the fraction is a lower bound on how busy the VALU is; the
-    measured cycles per instruction say the rest.  (Round 2 also printed a fraction of a "solo-class issue floor"; the kernel beat that
-    floor by 9 %, so it was a mis-model and is gone.)"""
+    measured cycles per instruction say the rest."""
     try:
         instr = json.load(open(CENSUS))["valu_instructions"]
     except (OSError, KeyError, ValueError):
@@ -67,14 +77,10 @@ def valu_roofline(perms_per_s):
             "cycles_per_valu_instruction_per_simd": 256 * 4 * 64 * CLOCK_HZ / lane_instr}
 
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of this bench (tools/collect_profiles.sh)
-
-
 def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (counters cannot be read from inside the process):
+    """HBM bytes per launch of `kernel` from the COMMITTED PMC passes (counters cannot be read from inside the process):
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) / algorithmic bytes, both per launch of the PMC pass,
-    applied to the algorithmic bytes per launch of THIS run (the passes ran 1 proof, a default run averages 7)."""
+    applied to the algorithmic bytes per launch of THIS run."""
     try:
         k = json.load(open(PMC_TRAFFIC))["kernels"][kernel]
         return k["traffic_over_algorithmic"] * algorithmic_bytes_per_launch
@@ -82,56 +88,148 @@ def pmc_traffic_bytes(kernel, algorithmic_bytes_per_launch):
         return None
 
 
-def real_lc_step(extra_committees=0, recursive=False, sync_committee_only=False):
-    """Not the headline number: the reference's own update pair 633 -> 634 through examples/lc_prover (the C++ host layer's
-    light-client circuit in its own SHA-256 layout), if the binary has been built.  The proof time includes the device-side witness
-    generation (K10).  extra_committees = 6 adds six more SyncCommitteeSSZ gadgets: 7 207 two_to_one_sha256, 2.24 M gates, 2^22 rows -
-    the reference's scale (README.md:71) made of real gadgets.  recursive: the circuit also verifies, as the reference's does, a proof
-    with the BLS proof's 25 216 public inputs (of the stand-in statement circuit: the BLS12-381 verifier itself is out of scope)."""
-    import re
-    import subprocess
-    import tempfile
-    exe = os.path.join(ROOT, "examples", "lc_prover")
-    golden = os.path.join(ROOT, "tests", "golden", "lc_updates.json")
-    if not (os.path.exists(exe) and os.path.exists(golden)):
-        return None
+def leaf_perms(degree_bits, proofs, builds=0, rate_bits=3):
+    """Poseidon permutations of the leaf hashing of `proofs` proofs (135 wires, 20 Z / partial-product columns, 16 quotient chunks: 17 + 3 + 2
+    per leaf) and `builds` build()s (84 or 85 constant and sigma columns: 11 per leaf) at 2^degree_bits rows"""
+    return float(1 << (degree_bits + rate_bits)) * (22 * proofs + 11 * builds)
+
+
+def leaf_hash_roofline(lh, perms):
+    """roofline block of k_hash_leaves (K4a, the dominant kernel of every workload here) from the HIP-event totals `lh` of its kernel
+    family {ms, launches, bytes} and the permutations those launches computed: algorithmic bytes per launch / average launch time against
+    the HBM peak (legitimately low: the kernel is integer-VALU bound), and the VALU fraction next to it."""
+    launches = max(lh["launches"], 1)
+    avg_ms = lh["ms"] / launches
+    per_launch = lh["bytes"] / launches
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    perms_per_s = perms / max(lh["ms"] * 1e-3, 1e-12)
+    traffic = pmc_traffic_bytes("k_hash_leaves", per_launch)
+    return {"bound": "valu", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_from_committed_pmc": True, "traffic_source": "profiles/r03_pmc_traffic.json (ratio of the PMC pass applied to this run's algorithmic bytes)",
+            "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": lh["launches"],
+            "note": "integer-VALU bound (Poseidon): `frac` is the HBM fraction the contract asks for and is legitimately low; `valu` is the bound that binds (DESIGN.md section 3)",
+            "valu": valu_roofline(perms_per_s)}
+
+
+def kernel_table(prof, steps):
+    out = {}
+    for k, v in prof.items():
+        if v["launches"]:
+            out[k] = {"ms_per_proof": round(v["ms"] / steps, 3), "scopes_per_proof": v["launches"] / steps,
+                      "algorithmic_GB_per_proof": round(v["bytes"] / steps / 1e9, 3), "achieved_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+    return out
+
+
+def prof_delta(p1, p0):
+    return {k: {f: p1[k][f] - p0[k][f] for f in ("ms", "launches", "bytes")} for k in p1}
+
+
+# ---------------------------------------------------------------- workloads on the C++ host layer (in-process, host/lc_capi.h)
+def light_client_workload(m, ctx, sync, flags=0, extra_committees=0, steps=3, warmup=1):
+    """`steps` timed data.prove(pw) of the light-client circuit for updates 633 -> 634 (+ extra SyncCommitteeSSZ gadgets); the last
+    proof is verified and its public inputs compared with the natively computed ones.  sync(): barrier + device synchronisation.
+    Returns (seconds for `steps` proofs, per-family profile delta, info, description)."""
+    import numpy as np
+    prev, cur = m.light_client.reference_updates()
+    step = m.light_client.LightClientStep(ctx, prev, cur, flags=flags, extra_committees=extra_committees)
+    for _ in range(warmup):
+        step.prove()
+    p0 = ctx.prof_get()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof, pis = step.prove()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = prof_delta(ctx.prof_get(), p0)
+    step.verify(proof, pis)  # raises if the GPU proof is not accepted
+    assert (np.asarray(pis) == step.expected_public_inputs).all(), "the proved public inputs are not the natively computed ones"
+    info = step.info
+    what = "light-client step for the reference's updates 633 -> 634 (add_virtual_proof_target + set_proof_target, 16 public inputs)"
+    if flags & m.light_client.SYNC_COMMITTEE_ONLY:
+        what = ("configs[1]: the SyncCommitteeSSZ gadget alone (512 pubkeys + aggregate key of update 634's next_sync_committee -> SSZ root, 1 025 two_to_one_sha256; "
+                "the reference's test_ssz_sync_committee), root = the native SSZ root")
+    if flags & m.light_client.BLS_PROOF_STAND_IN:
+        what += (" with the recursive verification of a 2^%d-row inner proof that has the BLS proof's %d public inputs (stand-in statement circuit: no statement about the "
+                 "signature; inner proof %.1f ms, not in ms_per_proof)" % (info.inner_degree_bits, info.inner_public_inputs, info.inner_prove_ms))
+    if extra_committees:
+        what += " + %d more SyncCommitteeSSZ gadgets" % extra_committees
+    what += ": %d gates, 2^%d rows; data.prove(pw) with witness generation inside (SHA-256 rows generated on the device), proof verified" % (info.num_gates, info.degree_bits)
+    out = (dt, prof, {"degree_bits": info.degree_bits, "gates": int(info.num_gates), "build_ms": round(info.build_ms, 1), "attach_ms": round(info.attach_ms, 1)}, what)
+    step.close()
+    return out
+
+
+def side_light_client(m, ctx, sync, **kw):
     try:
-        lc = json.load(open(golden))
-        with tempfile.TemporaryDirectory() as d:
-            paths = []
-            for tag in ("633", "634"):
-                paths.append(os.path.join(d, "u%s.json" % tag))
-                json.dump(lc[tag], open(paths[-1], "w"))
-            env = dict(os.environ, LCP2_PROF="1")
-            r = subprocess.run([exe] + paths + ["--repeat", "3", "--extra-committees", str(extra_committees)] + (["--bls-proof-stand-in"] if recursive else [])
-                               + (["--sync-committee-only"] if sync_committee_only else []),
-                               capture_output=True, text=True, timeout=600, env=env)
-        ms = [float(x) for x in re.findall(r"proved in ([0-9.]+) ms", r.stdout)]
-        bits = re.search(r"degree_bits (\d+)", r.stdout)
-        gates = re.search(r"(\d+) gates", r.stdout)
-        kern = {k: float(v) for k, v in re.findall(r"^\s+([a-z0-9_]+)\s+([0-9.]+) ms", r.stdout, re.M)}
-        if r.returncode != 0 or len(ms) < 3 or not bits:
-            return None
-        what = "light-client step for updates 633 -> 634 (examples/lc_prover)"
-        if sync_committee_only:
-            what = ("configs[1]: the SyncCommitteeSSZ gadget alone (512 pubkeys + aggregate key of update 634's next_sync_committee -> SSZ root, 1 025 "
-                    "two_to_one_sha256; the reference's test_ssz_sync_committee), root checked against the native SSZ root")
-        inner = re.search(r"inner proof .*: 2\^(\d+) rows, (\d+) public inputs, build ([0-9.]+) ms, inner prove ([0-9.]+) ms", r.stdout)
-        if recursive and inner:
-            what += (" with the recursive verification of a 2^%s-row inner proof that has the BLS proof's %s public inputs (stand-in statement circuit; "
-                     "inner proof %s ms, not in ms_per_proof)" % (inner.group(1), inner.group(2), inner.group(4)))
-        if extra_committees:
-            what += " + %d more SyncCommitteeSSZ gadgets: %s gates" % (extra_committees, gates.group(1) if gates else "?")
-        return {"workload": what + ", device witness generation included, proof verified", "degree_bits": int(bits.group(1)),
-                "ms_per_proof": min(ms[1:]), "kernel_ms_last_proof": kern}
-    except Exception:  # a side measurement must never take the bench line down
-        return None
+        dt, prof, info, what = light_client_workload(m, ctx, sync, steps=3, warmup=1, **kw)
+        return {"workload": what, "degree_bits": info["degree_bits"], "gates": info["gates"], "ms_per_proof": dt / 3 * 1e3,
+                "kernel_ms_per_proof": {k: round(v["ms"] / 3, 3) for k, v in prof.items() if v["launches"]},
+                "roofline": leaf_hash_roofline(prof["leaf_hash"], leaf_perms(info["degree_bits"], 3)), "host_build_ms": info["build_ms"], "device_build_ms": info["attach_ms"]}
+    except Exception as e:  # a side measurement must never take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+# ---------------------------------------------------------------- the synthetic circuits (lcp2_prove alone, witness resident in HBM)
+def synthetic_workload(m, ctx, sync, degree_bits, steps=3, host_witness=False):
+    """rounds 1-3's headline: `steps` lcp2_prove calls on the synthetic circuit over plonky2's own gate set, witness resident in HBM.
+    host_witness: additionally the same proofs with the witness in host memory (pinned double-buffered upload)."""
+    import numpy as np
+    import torch
+    params = m.standard_params(degree_bits, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3, small_values=True)
+    data = m.CircuitData.build(ctx, circ)
+    w_dev = torch.from_numpy(wires.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    data.prove(w_dev.data_ptr(), pis, mem=m.MEM_DEVICE)
+    p0 = ctx.prof_get()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = data.prove(w_dev.data_ptr(), pis, mem=m.MEM_DEVICE)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = prof_delta(ctx.prof_get(), p0)
+    data.verify(proof, pis)
+    out = {"workload": "synthetic satisfiable circuit over plonky2's own gate set (Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon; public inputs hashed "
+                       "in-circuit, real copy constraints), n=2^%d rows x 135 wires, witness resident in HBM: lcp2_prove alone (no witness generation), proof verified" % degree_bits,
+           "degree_bits": degree_bits, "ms_per_proof": dt / steps * 1e3, "kernels": kernel_table(prof, steps), "roofline": leaf_hash_roofline(prof["leaf_hash"], leaf_perms(degree_bits, steps))}
+    hw = None
+    if host_witness and hasattr(data, "prove_host_stream"):
+        try:
+            del w_dev
+            torch.cuda.empty_cache()
+            hw = data.host_witness_benchmark(wires, pis, steps=steps + 1, reference_proof=proof)
+            hw["device_resident_ms_per_proof"] = out["ms_per_proof"]
+            hw["host_over_device"] = hw["ms_per_proof_steady_state"] / out["ms_per_proof"]
+        except Exception as e:
+            hw = {"error": "%s: %s" % (type(e).__name__, e)}
+    data.close()
+    torch.cuda.empty_cache()
+    return out, hw
+
+
+def reference_gate_set(m, ctx, degree_bits):
+    try:
+        import reference_mix_probe as probe
+        out = probe.measure(ctx, degree_bits, reps=3)
+        out["generated_gate_kernels"] = probe.generated_gate_registers()
+        try:
+            pmc = json.load(open(REFERENCE_MIX_PMC))
+            out["k6_fetch_from_committed_pmc"] = {"source": "profiles/r04_reference_mix_k6.json (rocprofv3 --pmc FETCH_SIZE of tools/reference_mix_probe.py 22 1, doubled per the gfx950 correction)",
+                                                  "k6_read_GB_per_proof": pmc["k6_read_GB_per_proof"], "k6_algorithmic_GB_per_proof": pmc["k6_algorithmic_GB_per_proof"],
+                                                  "fetch_over_algorithmic": pmc["k6_read_GB_per_proof"] / pmc["k6_algorithmic_GB_per_proof"],
+                                                  "kernels": pmc["kernels"]}
+        except (OSError, KeyError, ValueError):
+            pass
+        return out
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps=3):
     """BASELINE configs[3]: one proof of the same circuit sharded over the `world` GPUs by LDE coset.  Every rank brings only its
     column shard of the witness (a slice of the resident tensor stands in for the column-sharded host upload)."""
-    import numpy as np
     import torch
     comm = m.parallel.TorchComm(dist, dev, ctx)
     form = comm.self_check()  # known-answer all-gather on a library buffer: "in-place", or "staged" if the aliased form misbehaves
@@ -161,8 +259,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
         m.CircuitData.verifier_only(circ, digest, cap).verify(proof, pis)  # raises if the assembled proof is not accepted
         ok = True
     prover.close()
-    n_words = 1 << (circ.params.degree_bits + circ.params.rate_bits)
-    return {"workload": "configs[3]: the same n=2^%d proof sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
+    return {"workload": "configs[3]: a n=2^%d proof (synthetic circuit over plonky2's gate set) sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
             "ms_per_proof": float(tt.item()) * 1e3, "world": world, "rccl_world_size": dist.get_world_size(), "proof_verified": ok,
             "all_gather_form": form, "witness_values_exchange": "all-to-all of row blocks" if rows else "all-gather of whole columns",
             "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
@@ -173,18 +270,50 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
                            "all_to_all_single: witness values as row blocks; " if rows else "")}
 
 
+def guarded(work, limit_s, on_timeout, exit_fn=os._exit):
+    """work() under a watchdog: if it has not returned after limit_s seconds, on_timeout(message) runs on the timer thread and the
+    process exits with code 3 (a collective that never completes cannot be interrupted from Python).  The decision "finished" /
+    "timed out" is taken once, under a lock: a timer that fires while work() is returning finds the work done and does nothing, and
+    the caller does not go on before the timer thread has either exited the process or returned."""
+    lock = threading.Lock()
+    state = {"done": False}
+
+    def give_up():
+        with lock:
+            if state["done"]:
+                return
+            state["done"] = True  # from here on the outcome is the timeout
+        on_timeout("did not finish within %s s (a collective hangs?)" % limit_s)
+        exit_fn(3)
+    timer = threading.Timer(limit_s, give_up)
+    timer.daemon = True
+    timer.start()
+    try:
+        return work()
+    finally:
+        with lock:
+            finished_first = not state["done"]
+            state["done"] = True
+        timer.cancel()
+        if not finished_first:
+            timer.join()  # the timeout won: its thread reports and exits the process (with a test's exit_fn it returns, and so do we)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--degree-bits", type=int, default=22)
+    ap.add_argument("--extra-committees", type=int, default=6, help="SyncCommitteeSSZ gadgets added to the light-client step of the headline: 6 -> 2.24 M gates, 2^22 rows")
+    ap.add_argument("--degree-bits", type=int, default=22, help="log2 rows of the synthetic side workloads (and of the sharded proof for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="also run the sharded-proof side measurement with one rank "
                     "(RCCL process group of size 1: exercises the N > 1 code path on a one-GPU box)")
     ap.add_argument("--cpu-sample-bits", type=int, default=18, help="log2 rows of the oracle's bounded sample")
-    ap.add_argument("--no-real-gadgets", action="store_true", help="skip the examples/lc_prover side measurements")
+    ap.add_argument("--no-real-gadgets", action="store_true", help="skip the light-client side workloads (2^19-row step, configs[1], recursive step)")
+    ap.add_argument("--no-synthetic", action="store_true", help="skip the synthetic side workloads (plonky2 gate set, reference gate set, host witness)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-proof measurement (configs[3]) after the replica run")
+    ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the 32-update batch (configs[4] as worded)")
     ap.add_argument("--launch-dry-run", action="store_true", help="start the rank processes, let each report the environment it was "
                     "given and exit before anything touches torch or the GPU (CPU test of the launcher)")
     return ap.parse_args()
@@ -204,8 +333,8 @@ def launch(a):
     processes of this same script (plain child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set: what
     torch.distributed.run would have set), waits for them and relays rank 0's JSON line.  It never imports torch and never makes
     a HIP call (a process that has initialised the GPU must not exec or be replaced; children are started, not exec'ed into).
-    A rank that fails ends the run with its exit code: the others are given a moment to fall out of their collectives, then
-    terminated by PID."""
+    A rank that fails ends the run with its exit code: the others are given 30 s to fall out of their collectives, then terminated
+    by PID, then - 20 s later - killed; LCP2_LAUNCH_DEADLINE_S (default 3000) bounds the whole wait, so the launcher always exits."""
     import subprocess
     assert "torch" not in sys.modules
     port = os.environ.get("MASTER_PORT") or str(_free_port())
@@ -218,7 +347,6 @@ def launch(a):
         # rank 0 (and, in a dry run, every rank) writes its line into a pipe; the other ranks' stdout joins stderr
         out = subprocess.PIPE if (r == 0 or a.launch_dry_run) else sys.stderr
         procs.append(subprocess.Popen(args, env=env, stdout=out))
-    import threading
     captured = {}
 
     def drain(r, pipe):  # a pipe nobody reads would block its writer once the buffer is full
@@ -227,7 +355,8 @@ def launch(a):
     readers = [threading.Thread(target=drain, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs) if p.stdout is not None]
     for t in readers:
         t.start()
-    rc, failed_at, terminated = 0, None, False
+    rc, failed_at, terminated_at, killed = 0, None, None, False
+    deadline = time.monotonic() + float(os.environ.get("LCP2_LAUNCH_DEADLINE_S", "3000"))
     live = set(range(a.gpus))
     while live:
         for r in sorted(live):
@@ -238,14 +367,25 @@ def launch(a):
             if code != 0 and rc == 0:
                 rc, failed_at = code, time.monotonic()
                 print("bench.py launcher: rank %d exited with code %d" % (r, code), file=sys.stderr)
-        if failed_at is not None and live and not terminated and time.monotonic() - failed_at > 30.0:
+        now = time.monotonic()
+        if live and now > deadline and failed_at is None:
+            rc, failed_at = 5, now - 30.0
+            print("bench.py launcher: deadline reached with ranks %s still running" % sorted(live), file=sys.stderr)
+        if failed_at is not None and live and terminated_at is None and now - failed_at > 30.0:
             for r in live:
                 procs[r].terminate()  # the exact PIDs this launcher started
-            terminated = True
+            terminated_at = now
+        if terminated_at is not None and live and not killed and now - terminated_at > 20.0:
+            for r in live:
+                procs[r].kill()  # a rank stuck in an uninterruptible driver call ignores SIGTERM
+            killed = True
+        if killed and live and now - terminated_at > 40.0:
+            print("bench.py launcher: ranks %s do not exit; giving up on them" % sorted(live), file=sys.stderr)
+            break
         if live:
             time.sleep(0.2)
     for t in readers:
-        t.join()
+        t.join(timeout=5.0)
     lines = [ln for r in sorted(captured) for ln in captured[r].splitlines() if ln.strip()]
     if a.launch_dry_run:
         kids = [json.loads(ln) for ln in lines]
@@ -260,14 +400,14 @@ def launch(a):
     return rc
 
 
-def cpu_baseline(sample_bits, degree_bits):
-    """Oracle prove() on a 2^sample_bits-row circuit of the same gate set, on min(32, cores) OpenMP threads (the reference's
+def cpu_baseline(m, ctx, sample_bits, degree_bits):
+    """Oracle prove() on a 2^sample_bits-row circuit of plonky2's gate set, on min(32, cores) OpenMP threads (the reference's
     published figure is for 32 vCPU, README.md:71), scaled to 2^degree_bits: the transforms (measured separately on the sample: the
     oracle's LDE of the 135 wire columns, x 1.4 for the Z / quotient / FRI columns) as n log n, everything else linearly in the row
-    count.  A 2^20-row sample would take ~2.5 minutes on the box, too long for the default run; 2^18 takes ~35 s."""
+    count (profiles/r04_cpu_baseline_scaling.json holds a measured 2^20 point next to this model).  The GPU proves the SAME sample
+    circuit and the two proofs must be equal word for word: whole-proof parity at 2^18 rows inside every default run."""
     import ctypes
     import numpy as np
-    import eth_lc_plonky2_amd as m
     import oracle_lib
     L = oracle_lib.load()
     params = m.standard_params(sample_bits, 4)
@@ -284,6 +424,10 @@ def cpu_baseline(sample_bits, degree_bits):
     proof = oc.prove(wires, pis)
     dt = time.perf_counter() - t0
     assert oc.verify(proof, pis) == 0
+    data = m.CircuitData.build(ctx, circ)
+    gpu_proof = data.prove(wires, pis)
+    equal = bool((gpu_proof == proof).all())
+    data.close()
     oc.close()
     n = 1 << sample_bits
     cols = np.ascontiguousarray(wires[:, :] % np.uint64(m.GOLDILOCKS_P))
@@ -295,10 +439,10 @@ def cpu_baseline(sample_bits, degree_bits):
     lg_s, lg_d = sample_bits + params.rate_bits, degree_bits + params.rate_bits
     rows = float(1 << (degree_bits - sample_bits))
     est = rows * ((dt - t_ntt) + t_ntt * lg_d / lg_s)
-    return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port",
-            "sample": "oracle prove() of the same gate set at 2^%d rows: %.2f s on %d OpenMP threads, of which transforms ~%.2f s; scaled to 2^%d rows "
-                      "(transforms x%d x %d/%d for n log n, the rest x%d): %.0f s per proof"
-                      % (sample_bits, dt, threads, t_ntt, degree_bits, int(rows), lg_d, lg_s, int(rows), est)}
+    return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port", "gpu_proof_equal": equal,
+            "sample": "oracle prove() of plonky2's gate set at 2^%d rows: %.2f s on %d OpenMP threads, of which transforms ~%.2f s; scaled to 2^%d rows "
+                      "(transforms x%d x %d/%d for n log n, the rest x%d): %.0f s per proof; the GPU proved the same sample: proofs %s word for word"
+                      % (sample_bits, dt, threads, t_ntt, degree_bits, int(rows), lg_d, lg_s, int(rows), est, "EQUAL" if equal else "DIFFER")}
 
 
 def main():
@@ -338,31 +482,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream(dev)
-    ctx = m.Context(local, stream=stream.cuda_stream)
+    ctx = m.Context(local, stream=stream.cuda_stream)  # raises without a GPU: there is no CPU fallback
     ctx.prof_enable(True)  # HIP-event timing of every kernel family from the first launch (same population as rocprofv3)
-
-    # ---- build(): circuit description on the host, preprocessed polynomials committed on the GPU (untimed)
-    params = m.standard_params(a.degree_bits, 4)
-    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3, small_values=True)
-    cs_dev = torch.from_numpy(circ.constants_sigmas.view(np.int64)).to(dev)
-    torch.cuda.synchronize()
-    data = m.CircuitData.build(ctx, circ, constants_sigmas_ptr=cs_dev.data_ptr(), mem=m.MEM_DEVICE)
-    if world == 1 and not a.force_sharded:
-        del cs_dev  # N > 1 keeps it for the sharded circuit built after the timed region
-    # each rank proves its own witness: the free cells of the padding row carry the (rank, update) tag
-    m.circuit.tag_witness(wires, rank + 1)
-    w_dev = torch.from_numpy(wires.view(np.int64)).to(dev)
-    torch.cuda.synchronize()
-    del wires  # 4.5 GB of host memory per rank; the witness lives in HBM from here on
-    circ.constants_sigmas = np.zeros((1, 1), dtype=np.uint64)  # 2.8 GB: the preprocessed columns are on the device too
-    torch.cuda.empty_cache()
-
-    def step():
-        return data.prove(w_dev.data_ptr(), pis, mem=m.MEM_DEVICE)
-
-    for _ in range(a.warmup):
-        step()
-    prof0 = ctx.prof_get()  # build() + warmup launches; subtracted for the per-proof table
 
     def barrier():
         torch.cuda.synchronize()
@@ -370,108 +491,123 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    proof = None
-    for _ in range(a.steps):
-        proof = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- the headline: data.prove(pw) of the 2^22-row circuit of real gadgets, witness generation inside the timed region
+    dt, prof, info, what = light_client_workload(m, ctx, barrier, flags=0, extra_committees=a.extra_committees, steps=a.steps, warmup=a.warmup)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ctx.prof_enable(False)
-    prof_all = ctx.prof_get()
-    prof = {k: {f: prof_all[k][f] - prof0[k][f] for f in ("ms", "launches", "bytes")} for k in prof_all}
-    data.verify(proof, pis)  # raises if the GPU proof is not accepted
-    sharded, rc = None, 0
     rccl_world = dist.get_world_size() if (world > 1 or a.force_sharded) else 1  # as the RCCL process group reports it
-    reported = []  # the JSON line goes out exactly once: normally after the sharded side measurement, or from its watchdog
+    prof_all = ctx.prof_get()  # every launch of the process so far (build, warm-up, timed steps): the population rocprofv3 --stats averages
+    lock = threading.Lock()
+    state = {"reported": False}  # the JSON line goes out exactly once: after the side measurements, or from the watchdog
 
-    def report(sharded):
-        if rank != 0 or reported:
+    def report(sharded, batch, from_watchdog=False):
+        with lock:
+            if state["reported"]:
+                return
+            state["reported"] = True
+        if rank != 0:
             return
-        reported.append(True)
-        nonlocal w_dev
         ms_per_step = dt / a.steps * 1e3
         value = world * a.steps / dt * 3600.0
-        lh = prof_all["leaf_hash"]  # every k_hash_leaves launch of this process, as rocprofv3 --stats averages them
-        avg_ms = lh["ms"] / max(lh["launches"], 1)
-        achieved = (lh["bytes"] / max(lh["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # the kernel is integer-VALU bound: permutations/s x instructions per permutation against the VALU issue peak
-        perms = (-(-params.num_wires // 8) + 3 + 2) * float(1 << (a.degree_bits + 3)) * a.steps  # wires, 20 Z columns, 16 quotient chunks
-        perms_per_s = perms / max(prof["leaf_hash"]["ms"] * 1e-3, 1e-12)
-        kern = {}
-        for k, v in prof.items():
-            if v["launches"]:
-                per = v["ms"] / a.steps
-                kern[k] = {"ms_per_proof": round(per, 3), "scopes_per_proof": v["launches"] / a.steps,
-                           "algorithmic_GB_per_proof": round(v["bytes"] / a.steps / 1e9, 3),
-                           "achieved_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
         out = {
             "metric": "lc_proofs_per_hour", "value": value, "unit": "proofs/hr", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[2]: full light-client-sized proof, n=2^%d rows x 135 wires, standard_recursion_config, "
-                                   "synthetic satisfiable circuit over plonky2's own gate set (Noop, Constant, PublicInput, BaseSum, Arithmetic, Poseidon; public inputs hashed in-circuit), recursive BLS verifier stubbed" % a.degree_bits,
-                       "degree_bits": a.degree_bits, "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
+            "vs_baseline": None, "dtype": "u64",
+            "data": "the reference's two real light-client updates (periods 633 -> 634, tests/golden/lc_updates.json); nothing synthetic in the headline",
+            "config": {"workload": "configs[2]: " + what + "; recursive BLS verifier stubbed",
+                       "degree_bits": info["degree_bits"], "gates": info["gates"], "proof_wall_time_s": ms_per_step / 1e3, "proof_verified": True,
+                       "witness_generation_in_timed_region": True, "host_build_ms": info["build_ms"], "device_build_ms": info["attach_ms"],
                        "parallelism": "replicas x%d (one independent proof per GPU)" % world,
                        "rccl_world_size": rccl_world, "replica_proofs_per_hour": value},
-            "roofline": {"bound": "hbm", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_hash_leaves", lh["bytes"] / max(lh["launches"], 1)),
-                         "algorithmic_bytes_per_launch": lh["bytes"] / max(lh["launches"], 1), "avg_launch_ms": avg_ms, "launches": lh["launches"],
-                         "note": "integer-VALU bound (Poseidon), so the HBM fraction is legitimately low: see `valu` and DESIGN.md section 3",
-                         "valu": valu_roofline(perms_per_s)},
-            "kernels": kern,
+            "roofline": leaf_hash_roofline(prof_all["leaf_hash"], leaf_perms(info["degree_bits"], a.warmup + a.steps, builds=1)),
+            "kernels": kernel_table(prof, a.steps),
         }
+        out["roofline"]["population"] = ("every k_hash_leaves launch of this process up to the end of the timed region (build, warm-up, steps): what `rocprofv3 --kernel-trace "
+                                         "--stats -- python3 bench.py --no-cpu-baseline --no-real-gadgets --no-synthetic` averages (profiles/r04_full_proof_kernel_stats.csv)")
         if sharded:
             out["config"]["sharded_proof"] = sharded
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample_bits, a.degree_bits), a.degree_bits)
-        if world == 1 and not a.no_real_gadgets:
-            data.close()  # the side measurements run in a child process: give the 92 GB workspace and the witness back first
-            w_dev = None
-            torch.cuda.empty_cache()
-            step_633 = real_lc_step()
-            if step_633:
-                out["config"]["real_lc_step"] = step_633
-            ssz = real_lc_step(sync_committee_only=True)
-            if ssz:
-                out["config"]["sync_committee_ssz"] = ssz
-            rec = real_lc_step(recursive=True)
-            if rec:
-                out["config"]["real_lc_step_recursive"] = rec
-            big = real_lc_step(extra_committees=6)
-            if big:
-                out["config"]["real_gadget_circuit_2p22"] = big
+        if batch:
+            out["config"]["batch_of_32"] = batch
+        if world == 1 and not from_watchdog:
+            sync = barrier
+            if not a.no_real_gadgets:
+                out["config"]["real_lc_step"] = side_light_client(m, ctx, sync)
+                out["config"]["sync_committee_ssz"] = side_light_client(m, ctx, sync, flags=m.light_client.SYNC_COMMITTEE_ONLY)
+                out["config"]["real_lc_step_recursive"] = side_light_client(m, ctx, sync, flags=m.light_client.BLS_PROOF_STAND_IN)
+            if not a.no_synthetic:
+                try:
+                    syn, hw = synthetic_workload(m, ctx, sync, a.degree_bits, host_witness=True)
+                    out["config"]["synthetic_plonky2_gate_set_2p%d" % a.degree_bits] = syn
+                    if hw:
+                        out["config"]["host_witness_2p%d" % a.degree_bits] = hw
+                except Exception as e:
+                    out["config"]["synthetic_plonky2_gate_set_2p%d" % a.degree_bits] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["config"]["reference_gate_set_2p%d" % a.degree_bits] = reference_gate_set(m, ctx, a.degree_bits)
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(m, ctx, min(a.cpu_sample_bits, a.degree_bits), a.degree_bits)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
-    if (world > 1 or a.force_sharded) and not a.no_sharded and (world & (world - 1)) == 0 and world <= (1 << params.rate_bits):
-        data.close()  # the replica's 92 GB workspace makes room for the sharded handle
-        torch.cuda.empty_cache()
+    sharded, batch, rc = None, None, 0
+    multi = (world > 1 or a.force_sharded)
+    if multi and not a.no_batch:
+        # BASELINE configs[4] as worded: a batch of 32 consecutive light-client updates data-parallel over the GPUs (32 / N per rank,
+        # no data-path collective, the finished proofs gathered on rank 0).  The reference ships ONE consecutive pair, so every update
+        # of the batch is that pair (the proofs are independent either way).
+        try:
+            prev, cur = m.light_client.reference_updates()
+            step = m.light_client.LightClientStep(ctx, prev, cur, flags=0, extra_committees=a.extra_committees)
+            step.prove()
+
+            class Updates:
+                num_updates = 32
+
+                def __call__(self, u):
+                    return u
+            barrier()
+            t0 = time.perf_counter()
+            proofs = m.batch.prove_batch(lambda u: step.prove()[0], Updates(), rank, world, dist if world > 1 else None, dev)
+            barrier()
+            bt = m.batch.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
+            ok = None
+            if rank == 0:
+                pis = step.expected_public_inputs
+                for p in (proofs[0], proofs[-1]):
+                    step.verify(p, pis)
+                ok = len(proofs) == 32
+            step.close()
+            batch = {"workload": "configs[4]: 32 light-client updates (each the reference's pair 633 -> 634 on the 2^%d-row circuit), %d per GPU over %d GPUs, "
+                                 "proofs gathered on rank 0" % (info["degree_bits"], -(-32 // world), world),
+                     "seconds": bt, "proofs_per_hour": 32 / bt * 3600.0, "all_32_proofs_gathered_first_and_last_verified": ok}
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            batch = {"error": "%s: %s" % (type(e).__name__, e)}
+    if multi and not a.no_sharded and (world & (world - 1)) == 0 and world <= 8:
         # A collective that never completes (this exchange has not run over RCCL with more than one rank yet) must not take the
         # replica result down with it: after LCP2_SHARDED_TIMEOUT_S the line goes out with the error and the rank exits non-zero.
-        import threading
+        limit = float(os.environ.get("LCP2_SHARDED_TIMEOUT_S", "300")) + (0.0 if rank == 0 else 5.0)
 
-        def give_up():
-            report({"error": "the sharded proof did not finish within %s s (a collective hangs?)" % limit})
-            os._exit(3)
-        limit = float(os.environ.get("LCP2_SHARDED_TIMEOUT_S", "240"))
-        watchdog = threading.Timer(limit if rank == 0 else limit + 5.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        def work():
+            params = m.standard_params(a.degree_bits, 4)
+            circ, wires, pis = m.circuit.synthetic_circuit(params, seed=3, small_values=True)
+            cs_dev = torch.from_numpy(circ.constants_sigmas.view(np.int64)).to(dev)
+            m.circuit.tag_witness(wires, rank + 1)
+            w_dev = torch.from_numpy(wires.view(np.int64)).to(dev)
+            torch.cuda.synchronize()
+            del wires
+            return sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
         try:
-            sharded = sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
+            sharded = guarded(work, limit, lambda why: report({"error": "the sharded proof " + why}, batch, from_watchdog=True))
         except Exception as e:  # the replica line still goes out, but the run fails: configs[3] is a first-class result for N > 1
             import traceback
             traceback.print_exc()
             sharded = {"error": "%s: %s" % (type(e).__name__, e)}
             rc = 3
-        finally:
-            watchdog.cancel()
+        torch.cuda.empty_cache()
 
-    report(sharded)
+    report(sharded, batch)
     if world > 1 or a.force_sharded:
         try:
             dist.destroy_process_group()

@@ -7,7 +7,7 @@ directory name follows the project ("eth-lc-plonky2_amd"); import it as
 """
 from .binding import (CircuitData, ProofRejected, Context, Lcp2Error, Oracle, Params, load_library, standard_params,  # noqa: F401
                       MEM_DEVICE, MEM_HOST, KERNEL_FAMILIES, GOLDILOCKS_P, proof_to_bytes, proof_from_bytes, proof_layout)
-from .build import build_native  # noqa: F401
+from .build import build_native, build_host  # noqa: F401
 from . import binding  # noqa: F401,E402
 from . import circuit  # noqa: F401,E402
 from . import poseidon_py  # noqa: F401,E402
@@ -15,3 +15,4 @@ from . import recursion_gates  # noqa: F401,E402
 from . import u32_gates  # noqa: F401,E402
 from . import batch  # noqa: F401,E402
 from . import parallel  # noqa: F401,E402
+from . import light_client  # noqa: F401,E402

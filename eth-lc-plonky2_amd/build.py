@@ -88,5 +88,26 @@ def build_native(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(PKG_DIR, "host")
+HOST_LIB = os.path.join(PKG_DIR, "liblcp2_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """eth-lc-plonky2_amd/liblcp2_host.so: the C++ host layer (CircuitBuilder, the reference's gadgets, light-client update ingestion,
+    witness generation) behind the C entry points of host/lc_capi.h, linked against liblcp2.so.  g++ only (no device code)."""
+    build_native(verbose=verbose)
+    srcs = sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cpp"))
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith((".hpp", ".h"))] + [os.path.join(PKG_DIR, "..", "include", "lcp2.h")]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", HOST_LIB + ".tmp"] + srcs + ["-L", PKG_DIR, "-llcp2", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(HOST_LIB + ".tmp", HOST_LIB)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -53,3 +53,37 @@ def test_a_failing_rank_fails_the_launch():
     assert r.returncode != 0
     assert "launcher: rank" in r.stderr
     assert not r.stdout.strip()
+
+
+def test_watchdog_reports_once_and_exits_when_the_work_hangs():
+    """bench.guarded: the sharded side measurement under its watchdog (LCP2_SHARDED_TIMEOUT_S).  A work function that outlives the
+    limit: the timeout line goes out once and the process exits with code 3, without waiting for the work."""
+    code = ("import os, sys, time; sys.path.insert(0, %r); import bench\n"
+            "bench.guarded(lambda: time.sleep(30), 0.05, lambda why: print('LINE ' + why, flush=True))\n"
+            "print('not reached')\n") % ROOT
+    t0 = __import__("time").time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=_env())
+    assert r.returncode == 3 and __import__("time").time() - t0 < 20
+    assert r.stdout.count("LINE ") == 1 and "not reached" not in r.stdout and "did not finish within 0.05 s" in r.stdout
+
+
+def test_watchdog_does_nothing_when_the_work_finishes_first():
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    events = []
+    assert bench.guarded(lambda: "done", 0.2, lambda why: events.append(("line", why)), exit_fn=lambda c: events.append(("exit", c))) == "done"
+    time.sleep(0.4)  # a timer that was not cancelled would fire here
+    assert events == []
+    # the timeout wins the race: its thread reports exactly once, and the caller waits for it instead of running on
+    # (with the real exit_fn the process is gone at that point)
+    out = bench.guarded(lambda: time.sleep(0.3) or "late", 0.05, lambda why: events.append(("line", why)), exit_fn=lambda c: events.append(("exit", c)))
+    assert out == "late" and [e[0] for e in events] == ["line", "exit"] and events[1][1] == 3
+    # an exception of the work is the caller's to handle; the watchdog stays quiet
+    events.clear()
+    try:
+        bench.guarded(lambda: 1 / 0, 0.2, lambda why: events.append(why), exit_fn=lambda c: events.append(c))
+    except ZeroDivisionError:
+        pass
+    time.sleep(0.4)
+    assert events == []

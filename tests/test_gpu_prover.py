@@ -62,6 +62,48 @@ def test_proof_equals_oracle(gpu_ctx, oracle, degree_bits):
     oc.close()
 
 
+def test_proof_equals_oracle_at_2p18(gpu_ctx, oracle):
+    """whole-proof parity at 2^18 rows (the sample bench.py's cpu_baseline leg proves on both sides: ~35 s of oracle time on the box's
+    32 threads): three-pass quotient iNTT, four FRI layers, every kernel family at a size where a proof has 2^21 leaves"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(18, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1, small_values=True)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    want = oc.prove(wires, pis)
+    data = m.CircuitData.build(gpu_ctx, circ)
+    got = data.prove(wires, pis)
+    assert _first_mismatch(m, params, got, want) is None, _first_mismatch(m, params, got, want)
+    assert oc.verify(got, pis) == 0
+    data.close()
+    oc.close()
+
+
+def test_light_client_step_in_process(gpu_ctx):
+    """host/lc_capi.h through eth_lc_plonky2_amd.light_client: the reference's main() flow in this process (what bench.py times) - build
+    the light-client circuit for updates 633 -> 634, data.prove(pw) with the witness generated inside, verify, public inputs = the
+    natively computed cur_state / new_state; the SyncCommitteeSSZ gadget alone gives the reference's KAT root 0x27afac05..."""
+    import eth_lc_plonky2_amd as m
+    prev, cur = m.light_client.reference_updates()
+    step = m.light_client.LightClientStep(gpu_ctx, prev, cur)
+    assert step.info.degree_bits == 19 and step.info.num_public_inputs == 16
+    proof, pis = step.prove()
+    step.verify(proof, pis)
+    assert (pis == step.expected_public_inputs).all()
+    proof2, _ = step.prove()
+    assert (proof2 == proof).all()  # deterministic (minimum proof-of-work witness)
+    bad = proof.copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(m.ProofRejected):
+        step.verify(bad, pis)
+    step.close()
+    ssz = m.light_client.LightClientStep(gpu_ctx, prev, cur, flags=m.light_client.SYNC_COMMITTEE_ONLY)
+    proof, pis = ssz.prove()
+    ssz.verify(proof, pis)
+    root = b"".join(int(w).to_bytes(4, "big") for w in pis)
+    assert root.hex() == "27afac05d6c340dd44d9b0515c667df438f4d5b3ac8fe7389649c6009eebaca9"  # src/sync_committee_pubkeys.rs:622
+    ssz.close()
+
+
 def test_workspace_reuse_and_device_resident_witness(gpu_ctx, oracle):
     import torch
     import eth_lc_plonky2_amd as m

@@ -87,6 +87,6 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     ctx = m.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     out = measure(ctx, bits, reps, native="--interpreted" not in sys.argv, compare_with_oracle="--oracle" in sys.argv)
-    if "--interpreted" not in sys.argv:
+    if "--interpreted" not in sys.argv and "--no-regs" not in sys.argv:  # (no child process under rocprofv3)
         out["generated_gate_kernels"] = generated_gate_registers()
     print(json.dumps(out))
