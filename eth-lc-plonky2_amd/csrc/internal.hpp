@@ -30,6 +30,10 @@ struct lcp2_ctx {
   bool prof_on = false;
   lcp2::ProfFamily fam[LCP2_K_COUNT];
   std::vector<hipEvent_t> event_pool;
+  // pinned host staging for the small device-to-host copies of a proof (caps, openings, flags, query answers): a copy into pinned
+  // memory is a plain DMA that the stream orders; into pageable memory the runtime stages it and blocks
+  void *pin = nullptr;
+  static constexpr size_t PIN_BYTES = 1u << 20;
 
   int fail(int code, const std::string &msg) {
     last_error = msg;

@@ -921,6 +921,72 @@ void launch_pow_search(hipStream_t s, const PowArgs &a, u64 count) {
   hipLaunchKernelGGL(k_pow_search, dim3((unsigned)(count / 256)), dim3(256), 0, s, a);
 }
 
+// ------------------------------------------------------------------ challenge-dependent setup (prover_kernels.hpp)
+__global__ void k_set_words(u64 *dst, SmallWords w, u32 n) {
+  if (threadIdx.x < n) dst[threadIdx.x] = w.v[threadIdx.x];
+}
+void launch_set_words(hipStream_t s, u64 *dst, const SmallWords &w, u32 n) {
+  hipLaunchKernelGGL(k_set_words, dim3(1), dim3(16), 0, s, dst, w, n);
+}
+
+__global__ __launch_bounds__(256) void k_quotient_setup(QuotientSetupArgs a) {
+  const u32 t = threadIdx.x, CH = a.num_challenges;
+  if (t < QUOTIENT_TERM_POWS) {  // alpha_c^t: the limb table and the first QUOTIENT_ALPHA_POWS plain powers
+    for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) {
+      const u64 pw = c < CH ? gl_pow(a.alphas[c], t) : 0;
+      u32 *w = a.limbs + ((size_t)c * QUOTIENT_TERM_POWS + t) * 4;
+      w[0] = (u32)(pw & 0x3FFFFF); w[1] = (u32)((pw >> 22) & 0x3FFFFF); w[2] = (u32)(pw >> 44); w[3] = 0;
+      if (t < QUOTIENT_ALPHA_POWS) a.small[SMALL_ALPHA_POW + (size_t)c * QUOTIENT_ALPHA_POWS + t] = pw;
+    }
+  } else if (t < 255) {          // alpha_c^(m_g - 1) for every gate g
+    for (u32 g = t - QUOTIENT_TERM_POWS; g < a.num_gates; g += 255 - QUOTIENT_TERM_POWS) {
+      const u32 m = konst((const u32 *)a.gates)[(size_t)g * (sizeof(GateDev) / 4) + 6];
+      for (u32 c = 0; c < QUOTIENT_MAX_CH; c++) a.small[SMALL_GATE_SCALE + (size_t)g * QUOTIENT_MAX_CH + c] = c < CH ? (m ? gl_pow(a.alphas[c], m - 1) : 1) : 0;
+    }
+  } else {                       // the scalars
+    for (u32 c = 0; c < 4; c++) {
+      const u64 al = c < CH ? a.alphas[c] : 0;
+      a.small[SMALL_ALPHAS + c] = al;
+      a.small[SMALL_ALPHA_INV + c] = al ? gl_inv(al) : 0;
+      a.small[SMALL_PI_HASH + c] = a.pi_hash[c];
+    }
+    a.small[SMALL_CHECK] = ~0ull;
+  }
+}
+void launch_quotient_setup(hipStream_t s, const QuotientSetupArgs &a) {
+  static_assert(QUOTIENT_TERM_POWS < 255 && QUOTIENT_MAX_CH <= 4 && QUOTIENT_ALPHA_POWS <= QUOTIENT_TERM_POWS, "k_quotient_setup's thread map");
+  hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void k_eval_tables(u64 z0, u64 z1, u32 chunk_len, u32 nchunks, u64 *tab) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  const gl2 z = gl2_make(z0, z1);
+  if (t < 256) { const gl2 v = gl2_pow(z, t); tab[2 * t] = v.c0; tab[2 * t + 1] = v.c1; }
+  else if (t - 256 < nchunks) { const u32 k = t - 256; const gl2 v = gl2_pow(z, (u64)chunk_len * k); tab[512 + 2 * k] = v.c0; tab[513 + 2 * k] = v.c1; }
+}
+void launch_eval_tables(hipStream_t s, u64 z0, u64 z1, u32 chunk_len, u32 nchunks, u64 *tab) {
+  hipLaunchKernelGGL(k_eval_tables, dim3((256 + nchunks + 255) / 256), dim3(256), 0, s, z0, z1, chunk_len, nchunks, tab);
+}
+
+__global__ __launch_bounds__(256) void k_compose_tables(u64 a0, u64 a1, u64 z0, u64 z1, u64 g, u32 total_polys, u32 h, u64 hi_count, u64 *T) {
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x, per = (1ull << h) + hi_count;
+  gl2 v;
+  if (t < total_polys) v = gl2_pow(gl2_make(a0, a1), t);
+  else {
+    const u64 r = t - total_polys, b = r / per, j = r % per;
+    if (b >= 4) return;
+    gl2 base = gl2_make(z0, z1);
+    if (b & 1) base = gl2_scale(base, g);
+    if (b & 2) base = gl2_inv(base);
+    v = j < (1ull << h) ? gl2_pow(base, j) : gl2_pow(base, (j - (1ull << h)) << h);
+  }
+  T[2 * t] = v.c0; T[2 * t + 1] = v.c1;
+}
+void launch_compose_tables(hipStream_t s, u64 a0, u64 a1, u64 z0, u64 z1, u64 g, u32 total_polys, u32 h, u64 hi_count, u64 *T) {
+  const u64 entries = total_polys + 4 * ((1ull << h) + hi_count);
+  hipLaunchKernelGGL(k_compose_tables, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, a0, a1, z0, z1, g, total_polys, h, hi_count, T);
+}
+
 __global__ void k_fill(u64 *p, u64 n, u64 v) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

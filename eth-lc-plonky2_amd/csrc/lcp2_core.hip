@@ -62,6 +62,7 @@ extern "C" int lcp2_ctx_create_ex(int device, void *stream, uint32_t flags, lcp2
     if (hipStreamCreateWithFlags(&ctx->stream, how) != hipSuccess) { delete ctx; return LCP2_E_HIP; }
     ctx->own_stream = true;
   }
+  if (hipHostMalloc(&ctx->pin, lcp2_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->pin = nullptr;  // without it copies go to pageable memory
   u64 rc[POS_RC_WORDS];  // the 360 round constants, then the group constants of the partial rounds (poseidon.hpp)
   pos_derive_round_constants(rc);
   pos_extend_round_constants(rc);
@@ -83,6 +84,7 @@ extern "C" void lcp2_ctx_destroy(lcp2_ctx *ctx) {
     for (auto &pr : f.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_rc) (void)hipFree(ctx->d_rc);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

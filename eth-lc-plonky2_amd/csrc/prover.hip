@@ -39,7 +39,7 @@ struct lcp2_circuit {
   lcp2_oracle cs;  // constants_sigmas commitment
   // device: per-proof workspace (allocated once)
   lcp2_oracle wires, zs, quot;
-  DevBuf wires_vals, zs_vals, chunk_q, row_tot, scan_tmp, qvals, planes, small, partial, tables, alpha_limbs;
+  DevBuf wires_vals, zs_vals, chunk_q, row_tot, scan_tmp, qvals, planes, small, partial, tables, alpha_limbs, open_out;
   DevBuf fri_c[2];                       // ping-pong coefficient planes [2][m]
   std::vector<DevBuf> fri_vals, fri_dig; // per layer: value planes [2][8 m_l], digests
   std::vector<std::vector<u64>> fri_level_off;
@@ -68,6 +68,8 @@ struct lcp2_circuit {
   DevBuf q_combine;  // the combining matrix [R][R] (k_quotient_combine)
   bool local_quotient() const { return sharded() && p.rate_bits <= 3; }
   u64 perm_wrap[2 * QUOTIENT_MAX_CH] = {0};  // per challenge: Z before the block's last row, the last row's quotient (host)
+  u64 noncanon_host = 0;   // stage_wires: a witness value was >= p (arrives with the wires cap)
+  bool check_pending = false;  // the gate-check verdict of stage_quotient_values has not been read yet (it arrives with the quotient cap)
   uint32_t world() const { return bc ? (1u << p.rate_bits) / bc : 1; }
   uint32_t rank() const { return bc ? bf / bc : 0; }
   u64 rows() const { return rows_mode ? (1ull << p.degree_bits) / world() : (1ull << p.degree_bits); }
@@ -103,10 +105,6 @@ const char *params_problem(const lcp2_params &p, bool *unsupported) {
 namespace {
 #define LCP2_TRY(expr) do { int rc_ = (expr); if (rc_ != LCP2_OK) return rc_; } while (0)
 
-// word offsets inside lcp2_circuit::small (per-proof scalars on the device)
-constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
-                 SMALL_CHECK = 21, SMALL_NONCANON = 22, SMALL_PERM_PREFIX = 24, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
-
 inline u32 npp_of(const lcp2_params &p) { return (p.num_routed_wires + p.quotient_degree_factor - 1) / p.quotient_degree_factor - 1; }
 
 int check_params(lcp2_ctx *ctx, const lcp2_params &p) {
@@ -135,10 +133,39 @@ int upload(lcp2_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
   if (bytes) LCP2_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return LCP2_OK;
 }
+// Device-to-host copies of a proof go through the context's pinned staging buffer: the pieces of one transcript step (a cap and a
+// flag, all the openings, ...) are queued back to back and arrive with ONE synchronisation of the stream.
+struct Download {
+  lcp2_ctx *ctx;
+  struct Piece { void *dst; size_t off, bytes; };
+  std::vector<Piece> pieces;
+  size_t used = 0;
+  bool direct = false;  // a piece did not fit the staging buffer (or there is none): it went straight to its destination
+  explicit Download(lcp2_ctx *c) : ctx(c) {}
+  int add(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return LCP2_OK;
+    if (!ctx->pin || used + bytes > lcp2_ctx::PIN_BYTES) {
+      LCP2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      direct = true;
+      return LCP2_OK;
+    }
+    LCP2_HIP(ctx, hipMemcpyAsync((char *)ctx->pin + used, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    pieces.push_back({dst, used, bytes});
+    used += (bytes + 7) & ~(size_t)7;
+    return LCP2_OK;
+  }
+  int wait() {  // the one synchronisation; the staged pieces land in their destinations
+    LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (const Piece &q : pieces) memcpy(q.dst, (const char *)ctx->pin + q.off, q.bytes);
+    pieces.clear();
+    used = 0;
+    return LCP2_OK;
+  }
+};
 int download(lcp2_ctx *ctx, void *dst, const void *src, size_t bytes) {
-  LCP2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return LCP2_OK;
+  Download d(ctx);
+  LCP2_TRY(d.add(dst, src, bytes));
+  return d.wait();
 }
 
 // two-level extension power tables: lo[j] = z^j (j < 2^h), hi[j] = z^(j << h) (j <= count >> h), interleaved [c0, c1]
@@ -207,12 +234,17 @@ static const char *validate_programs(const lcp2_circuit_desc *d) {
 
 // cap of oracle `o` into a full-size cap buffer: a sharded circuit writes its own entries at their global position and
 // zeros elsewhere (its share: the caps of all ranks OR-ed together are the cap)
-static int download_cap(lcp2_circuit *c, const lcp2_oracle &o, u64 *dst) {
+static int queue_cap(Download &d, lcp2_circuit *c, const lcp2_oracle &o, u64 *dst) {
   const size_t capw = (size_t)4 << c->p.cap_height;
-  if (!c->sharded()) return download(c->ctx, dst, o.cap_dev(), capw * 8);
+  if (!c->sharded()) return d.add(dst, o.cap_dev(), capw * 8);
   const size_t per_block = (size_t)4 << (c->p.cap_height - c->p.rate_bits);
   memset(dst, 0, capw * 8);
-  return download(c->ctx, dst + c->bf * per_block, o.cap_dev(), per_block * c->bc * 8);
+  return d.add(dst + c->bf * per_block, o.cap_dev(), per_block * c->bc * 8);
+}
+static int download_cap(lcp2_circuit *c, const lcp2_oracle &o, u64 *dst) {
+  Download d(c->ctx);
+  LCP2_TRY(queue_cap(d, c, o, dst));
+  return d.wait();
 }
 
 // circuit_builder.rs::build: circuit_digest = hash_no_pad(constants_sigmas_cap || domain_separator_digest || degree_bits) with
@@ -489,28 +521,25 @@ int open_oracle(lcp2_ctx *ctx, lcp2_oracle &o, const u64 *d_idx, u32 k, u64 *d_l
   return LCP2_OK;
 }
 
-// evaluate every coefficient column of `o` (or its first `ncols`) at z; results (ext) land in d_out[2 * ncols]
-int eval_columns(lcp2_circuit *c, const u64 *coeffs, u32 ncols, gl2 z, u64 *d_out, u64 *d_tab) {
-  lcp2_ctx *ctx = c->ctx;
+// evaluate `ncols` coefficient columns at z; results (ext) land in d_out[2 * ncols].  d_tab: the power tables of z (eval_tables)
+u32 eval_chunk_len(u64 n) { return (u32)std::min<u64>(n, EVAL_CHUNK); }
+size_t eval_table_words(u64 n) { return 512 + 2 * (size_t)(n / eval_chunk_len(n)); }
+void eval_tables(lcp2_circuit *c, gl2 z, u64 *d_tab) {  // z travels in the kernel arguments: no staging copy, no synchronisation
+  const u64 n = 1ull << c->p.degree_bits;
+  launch_eval_tables(c->ctx->stream, z.c0, z.c1, eval_chunk_len(n), (u32)(n / eval_chunk_len(n)), d_tab);
+}
+void eval_columns(lcp2_circuit *c, const u64 *coeffs, u32 ncols, gl2 z, u64 *d_out, const u64 *d_tab) {
   const u64 n = 1ull << c->p.degree_bits;
   EvalArgs a{};
   a.coeffs = coeffs; a.col_stride = n;
-  a.chunk_len = (u32)std::min<u64>(n, EVAL_CHUNK);
+  a.chunk_len = eval_chunk_len(n);
   a.items = (a.chunk_len + 255) / 256;
   a.nchunks = (u32)(n / a.chunk_len);
-  std::vector<u64> t;
-  gl2 cur = gl2_make(1, 0);
-  for (int i = 0; i < 256; i++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, z); }
-  a.zstep[0] = cur.c0; a.zstep[1] = cur.c1;  // z^256
-  gl2 zc = gl2_pow(z, a.chunk_len);
-  cur = gl2_make(1, 0);
-  for (u32 k = 0; k < a.nchunks; k++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, zc); }
-  LCP2_HIP(ctx, hipMemcpyAsync(d_tab, t.data(), t.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `t` is a stack-lifetime staging buffer
+  const gl2 zs = gl2_pow(z, 256);
+  a.zstep[0] = zs.c0; a.zstep[1] = zs.c1;
   a.zpow_t = d_tab; a.zpow_chunk = d_tab + 512;
   a.partial = c->partial.u();
-  launch_eval_polys(ctx->stream, a, ncols, d_out);
-  return LCP2_OK;
+  launch_eval_polys(c->ctx->stream, a, ncols, d_out);
 }
 }  // namespace
 
@@ -551,7 +580,7 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
   // check of the quotient stage does not.  The bit-reversal of the iNTT, which reads every value anyway, reports whether one is
   // >= p (no extra traffic); stage_perm_zs then takes a canonical copy before anything reads the values again.
   unsigned long long *d_flag = (unsigned long long *)(c->small.u() + SMALL_NONCANON);
-  LCP2_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, s));
+  launch_set_words(s, c->small.u() + SMALL_NONCANON, SmallWords{}, 1);
   if (d_coeffs) {
     LCP2_TRY(commit_coeffs_dev(ctx, d_coeffs, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, true));
     launch_canon_copy(s, d_wires, nullptr, (u64)W * c->rows(), d_flag);  // the values did not pass through an iNTT here: scan them
@@ -564,7 +593,12 @@ int stage_wires(lcp2_circuit *c, const u64 *wires_in, lcp2_mem wires_mem, const 
   } else {
     LCP2_TRY(commit_values_dev(ctx, d_wires, W, p.degree_bits, p.rate_bits, p.cap_height, &c->wires, d_flag));
   }
-  LCP2_TRY(download_cap(c, c->wires, cap_out));
+  {  // the cap and the non-canonical flag with one synchronisation
+    Download d(ctx);
+    LCP2_TRY(queue_cap(d, c, c->wires, cap_out));
+    LCP2_TRY(d.add(&c->noncanon_host, d_flag, 8));
+    LCP2_TRY(d.wait());
+  }
   c->d_wires_cur = d_wires;
   c->stage = lcp2_circuit::ST_WIRES;
   return LCP2_OK;
@@ -599,14 +633,13 @@ int perm_begin(lcp2_circuit *c, const u64 *betas, const u64 *gammas) {
   if (c->stage < lcp2_circuit::ST_WIRES) return ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs: the wires are not committed");
   const u64 R = c->rows();
   u64 *d_small = c->small.u();
-  u64 bc[4] = {0}, gc[4] = {0};
-  for (u32 k = 0; k < CH; k++) { bc[k] = gl_canon(betas[k]); gc[k] = gl_canon(gammas[k]); }
-  LCP2_HIP(ctx, hipMemcpyAsync(d_small + SMALL_BETAS, bc, CH * 8, hipMemcpyHostToDevice, s));
-  LCP2_HIP(ctx, hipMemcpyAsync(d_small + SMALL_GAMMAS, gc, CH * 8, hipMemcpyHostToDevice, s));
-  u64 noncanonical = 0;
-  LCP2_HIP(ctx, hipMemcpyAsync(&noncanonical, d_small + SMALL_NONCANON, 8, hipMemcpyDeviceToHost, s));
-  LCP2_HIP(ctx, hipStreamSynchronize(s));
-  if (noncanonical) {  // rare: a witness with values in [p, 2^64): continue from a canonical copy (stage_wires)
+  {  // the challenges travel in the kernel arguments (betas at SMALL_BETAS, gammas right behind them)
+    static_assert(SMALL_GAMMAS == SMALL_BETAS + 4 && QUOTIENT_MAX_CH <= 4, "betas and gammas are set with one launch");
+    SmallWords w{};
+    for (u32 k = 0; k < CH; k++) { w.v[k] = gl_canon(betas[k]); w.v[4 + k] = gl_canon(gammas[k]); }
+    launch_set_words(s, d_small + SMALL_BETAS, w, 8);
+  }
+  if (c->noncanon_host) {  // rare: a witness with values in [p, 2^64): continue from a canonical copy (stage_wires)
     LCP2_HIP(ctx, c->wires_vals.ensure((size_t)W * R * 8));
     launch_canon_copy(s, c->d_wires_cur, c->wires_vals.u(), (u64)W * R, nullptr);  // (a host witness is already the library's copy: in place)
     c->d_wires_cur = c->wires_vals.u();
@@ -622,9 +655,16 @@ int perm_begin(lcp2_circuit *c, const u64 *betas, const u64 *gammas) {
     launch_scan(s, true, c->row_tot.u(), zs_out, c->scan_tmp.u(), R, false, CH, R);
   }
   LCP2_HIP(ctx, hipGetLastError());
-  for (u32 k = 0; k < CH; k++) {  // lands with the caller's next synchronisation of the stream
-    LCP2_HIP(ctx, hipMemcpyAsync(&c->perm_wrap[2 * k], zs_out + (u64)k * R + (R - 1), 8, hipMemcpyDeviceToHost, s));
-    LCP2_HIP(ctx, hipMemcpyAsync(&c->perm_wrap[2 * k + 1], c->row_tot.u() + (u64)k * R + (R - 1), 8, hipMemcpyDeviceToHost, s));
+  return LCP2_OK;
+}
+// Z before the block's last row and that row's quotient, per challenge, into c->perm_wrap: queued behind whatever the caller
+// downloads next (perm_finalize rescales zs_out in place only when a prefix is given, and then the caller has read these first)
+int queue_perm_wrap(Download &d, lcp2_circuit *c) {
+  const u64 R = c->rows();
+  const u64 *zs_out = perm_out(c);
+  for (u32 k = 0; k < c->p.num_challenges; k++) {
+    LCP2_TRY(d.add(&c->perm_wrap[2 * k], zs_out + (u64)k * R + (R - 1), 8));
+    LCP2_TRY(d.add(&c->perm_wrap[2 * k + 1], c->row_tot.u() + (u64)k * R + (R - 1), 8));
   }
   return LCP2_OK;
 }
@@ -635,8 +675,9 @@ int perm_finish(lcp2_circuit *c, const u64 *prefix) {
   PermArgs a = perm_args(c, ntt, perm_out(c));
   if (be.status) return be.status;
   if (prefix) {
-    LCP2_HIP(ctx, hipMemcpyAsync(c->small.u() + SMALL_PERM_PREFIX, prefix, CH * 8, hipMemcpyHostToDevice, s));
-    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `prefix` is the caller's
+    SmallWords w{};
+    for (u32 k = 0; k < CH; k++) w.v[k] = prefix[k];
+    launch_set_words(s, c->small.u() + SMALL_PERM_PREFIX, w, CH);
     a.prefix = c->small.u() + SMALL_PERM_PREFIX;
   }
   ProfScope ps(ctx, LCP2_K_PERM_Z, (double)c->rows() * 8.0 * CH * (1.0 + 2.0 * npp));
@@ -645,7 +686,7 @@ int perm_finish(lcp2_circuit *c, const u64 *prefix) {
   return LCP2_OK;
 }
 
-int perm_commit(lcp2_circuit *c, u64 *cap_out) {
+int perm_commit(lcp2_circuit *c, u64 *cap_out, bool with_wrap = false) {
   LCP2_STAGE_PROLOGUE
   const u32 ncz = CH * (1 + npp);
   if (c->rows_mode) {  // the exchange buffer holds every rank's rows, [rank][column][rows]: back to whole columns
@@ -654,7 +695,10 @@ int perm_commit(lcp2_circuit *c, u64 *cap_out) {
       launch_copy_2d(s, c->zs_vals.u() + (u64)r * R, n, c->zs_rows.u() + (u64)r * ncz * R, R, R, ncz);
   }
   LCP2_TRY(commit_values_dev(ctx, c->zs_vals.u(), ncz, p.degree_bits, p.rate_bits, p.cap_height, &c->zs));
-  LCP2_TRY(download_cap(c, c->zs, cap_out));  // synchronises the stream
+  Download d(ctx);
+  LCP2_TRY(queue_cap(d, c, c->zs, cap_out));
+  if (with_wrap) LCP2_TRY(queue_perm_wrap(d, c));  // (the commitment reads zs_vals, it does not change it)
+  LCP2_TRY(d.wait());
   c->stage = lcp2_circuit::ST_ZS;
   return LCP2_OK;
 }
@@ -663,7 +707,7 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
   if (c->rows_mode) return c->ctx->fail(LCP2_E_INVALID, "row exchange form: lcp2_perm_zs_rows_begin / _finish / lcp2_perm_zs_commit");
   LCP2_TRY(perm_begin(c, betas, gammas));
   LCP2_TRY(perm_finish(c, nullptr));
-  LCP2_TRY(perm_commit(c, cap_out));  // synchronises the stream: perm_wrap has landed
+  LCP2_TRY(perm_commit(c, cap_out, true));  // one synchronisation: the cap and perm_wrap
   // Copy constraints: Z must come back to 1 after the last row, Z(g^(n-1)) * (row n-1's quotient) = 1, which holds for
   // every beta, gamma exactly when the wire values are constant on the cycles of sigma (up to the soundness error of the
   // argument itself).  plonky2 reports a broken copy constraint as an Err of prove(); so does this (LCP2_E_UNSAT).
@@ -676,30 +720,22 @@ int stage_perm_zs(lcp2_circuit *c, const u64 *betas, const u64 *gammas, u64 *cap
 }
 
 // compute_quotient_polys + commitment (K6, K1-K4)
-int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash) {
+// defer_check: leave the gate-check verdict on the device; stage_quotient_commit reads it together with the quotient cap
+int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash, bool defer_check = false) {
   LCP2_STAGE_PROLOGUE
   if (c->stage < lcp2_circuit::ST_ZS) return ctx->fail(LCP2_E_INVALID, "lcp2_quotient: Z / partial products are not committed");
   u64 *d_small = c->small.u();
   u64 *d_betas = d_small + SMALL_BETAS, *d_gammas = d_small + SMALL_GAMMAS, *d_alphas = d_small + SMALL_ALPHAS;
   const u32 NG = (u32)c->gates.size();
-  {  // alphas, their inverses, the public-input hash, the check flag and alpha^(m_g - 1) per gate: one small upload
-    std::vector<u64> h(SMALL_GATE_SCALE - SMALL_ALPHAS + (size_t)QUOTIENT_MAX_CH * NG, 0);
-    for (u32 k = 0; k < CH; k++) {
-      const u64 al = gl_canon(alphas[k]);
-      h[k] = al;
-      h[SMALL_ALPHA_INV - SMALL_ALPHAS + k] = al ? gl_inv(al) : 0;
-      for (u32 g = 0; g < NG; g++)
-        h[SMALL_GATE_SCALE - SMALL_ALPHAS + (size_t)g * QUOTIENT_MAX_CH + k] = c->gates[g].num_constraints ? gl_pow(al, c->gates[g].num_constraints - 1) : 1;
-      u64 pw = 1;
-      for (u32 e = 0; e < QUOTIENT_ALPHA_POWS; e++) { h[SMALL_ALPHA_POW - SMALL_ALPHAS + (size_t)k * QUOTIENT_ALPHA_POWS + e] = pw; pw = gl_mul(pw, al); }
-    }
-    for (u32 i = 0; i < 4; i++) h[SMALL_PI_HASH - SMALL_ALPHAS + i] = gl_canon(pi_hash[i]);
-    h[SMALL_CHECK - SMALL_ALPHAS] = ~0ull;
-    const std::vector<uint32_t> limbs = alpha_limb_table(alphas, CH);
-    LCP2_HIP(ctx, c->alpha_limbs.ensure(limbs.size() * 4));
-    LCP2_HIP(ctx, hipMemcpyAsync(c->alpha_limbs.p, limbs.data(), limbs.size() * 4, hipMemcpyHostToDevice, s));
-    LCP2_HIP(ctx, hipMemcpyAsync(d_alphas, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
-    LCP2_HIP(ctx, hipStreamSynchronize(s));  // `h` and `limbs` are stack-lifetime staging buffers
+  {  // alphas, their inverses and powers, the limb table, the public-input hash, the check flag, alpha^(m_g - 1) per gate: computed
+     // on the device from the challenges in the kernel arguments (k_quotient_setup)
+    QuotientSetupArgs qs{};
+    for (u32 k = 0; k < CH; k++) qs.alphas[k] = gl_canon(alphas[k]);
+    for (u32 i = 0; i < 4; i++) qs.pi_hash[i] = gl_canon(pi_hash[i]);
+    qs.num_challenges = CH; qs.num_gates = NG; qs.gates = (const GateDev *)c->d_gates.p; qs.small = d_small;
+    LCP2_HIP(ctx, c->alpha_limbs.ensure((size_t)QUOTIENT_MAX_CH * QUOTIENT_TERM_POWS * 16));
+    qs.limbs = (u32 *)c->alpha_limbs.p;
+    launch_quotient_setup(s, qs);
   }
   // ---- K6: quotient values on the coset, coset iNTT, chunking, commitment
   {
@@ -734,9 +770,12 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     }
     if (be.status) return be.status;
   }
-  u64 bad_row = ~0ull;
-  LCP2_TRY(download(ctx, &bad_row, d_small + SMALL_CHECK, 8));  // synchronises the stream
-  if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1 + c->row0()));
+  c->check_pending = defer_check;
+  if (!defer_check) {
+    u64 bad_row = ~0ull;
+    LCP2_TRY(download(ctx, &bad_row, d_small + SMALL_CHECK, 8));  // synchronises the stream
+    if (bad_row != ~0ull) return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1 + c->row0()));
+  }
   c->stage = lcp2_circuit::ST_QVALS;
   return LCP2_OK;
 }
@@ -768,14 +807,26 @@ int stage_quotient_commit(lcp2_circuit *c, u64 *cap_out) {
   if (be.status) return be.status;
   // N = Q n: the 8n coefficients of challenge c are exactly its Q chunks of n coefficients, already contiguous
   LCP2_TRY(commit_coeffs_dev(ctx, c->quot.coeffs.u(), CH * Q, p.degree_bits, p.rate_bits, p.cap_height, &c->quot, false));
-  LCP2_TRY(download_cap(c, c->quot, cap_out));
+  u64 bad_row = ~0ull;
+  {
+    Download d(ctx);
+    LCP2_TRY(queue_cap(d, c, c->quot, cap_out));
+    if (c->check_pending) LCP2_TRY(d.add(&bad_row, c->small.u() + SMALL_CHECK, 8));
+    LCP2_TRY(d.wait());
+  }
+  if (c->check_pending && bad_row != ~0ull) {  // plonky2 would have produced an invalid proof here; this is the Err of prove()
+    c->check_pending = false;
+    c->stage = lcp2_circuit::ST_ZS;
+    return ctx->fail(LCP2_E_UNSAT, "the witness violates a gate constraint on row " + std::to_string(bad_row - 1 + c->row0()));
+  }
+  c->check_pending = false;
   c->stage = lcp2_circuit::ST_QUOT;
   return LCP2_OK;
 }
 
 int stage_quotient(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash, u64 *cap_out) {
   if (c->sharded()) return c->ctx->fail(LCP2_E_INVALID, "sharded circuit: use lcp2_quotient_values, exchange the buffer, then lcp2_quotient_commit");
-  LCP2_TRY(stage_quotient_values(c, alphas, pi_hash));
+  LCP2_TRY(stage_quotient_values(c, alphas, pi_hash, true));  // the verdict of the gate check arrives with the cap: one synchronisation
   return stage_quotient_commit(c, cap_out);
 }
 
@@ -807,31 +858,39 @@ int fri_open_openings(lcp2_circuit *c, u64 *proof) {
   const gl2 zeta = fo.zeta, g_zeta = gl2_scale(zeta, gl_root_of_unity(p.degree_bits));
   lcp2_oracle *oracles[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
   memset(proof + L.op_constants, 0, (L.total - L.op_constants) * 8);
-  u64 *d_tab = c->tables.u();
-  u64 *d_open = c->partial.u() + c->partial.bytes / 8 - 2 * (size_t)std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q));
-  std::vector<u64> tmp(2 * std::max(std::max(ncs, W), std::max(CH * (1 + npp), CH * Q)));
+  // the power tables of zeta and g zeta (device-made), every oracle's columns evaluated back to back, ONE copy back
+  u64 *d_tab = c->tables.u(), *d_tab_g = d_tab + eval_table_words(n);
+  const u32 all_cols = ncs + W + CH * (1 + npp) + CH * Q + CH;
+  LCP2_HIP(ctx, c->open_out.ensure((size_t)2 * all_cols * 8));
+  u64 *d_open = c->open_out.u();
+  std::vector<u64> tmp((size_t)2 * all_cols);
   u32 share_cols = 0;
   for (int o = 0; o < 4; o++) { u32 f, k; column_share(c, oracles[o]->ncols, f, k); share_cols += k; }
   ProfScope ps(ctx, LCP2_K_OPENINGS, 8.0 * n * (share_cols + CH));
+  eval_tables(c, zeta, d_tab);
+  const bool with_next = !c->sharded() || c->bf == 0;
+  if (with_next) eval_tables(c, g_zeta, d_tab_g);
+  u32 at_col[5], first_col[4], num_cols[4], pos = 0;
   for (int o = 0; o < 4; o++) {
-    u32 first, nc;
-    column_share(c, oracles[o]->ncols, first, nc);
-    if (!nc) continue;
-    LCP2_TRY(eval_columns(c, oracles[o]->coeffs.u() + (size_t)first * n, nc, zeta, d_open, d_tab));
-    LCP2_TRY(download(ctx, tmp.data(), d_open, 2 * nc * 8));
-    for (u32 j = 0; j < nc; j++) {
-      const u32 col = first + j;
+    column_share(c, oracles[o]->ncols, first_col[o], num_cols[o]);
+    at_col[o] = pos;
+    if (num_cols[o]) eval_columns(c, oracles[o]->coeffs.u() + (size_t)first_col[o] * n, num_cols[o], zeta, d_open + 2 * pos, d_tab);
+    pos += num_cols[o];
+  }
+  at_col[4] = pos;
+  if (with_next) { eval_columns(c, c->zs.coeffs.u(), CH, g_zeta, d_open + 2 * pos, d_tab_g); pos += CH; }
+  LCP2_HIP(ctx, hipGetLastError());
+  LCP2_TRY(download(ctx, tmp.data(), d_open, (size_t)2 * pos * 8));
+  for (int o = 0; o < 4; o++)
+    for (u32 j = 0; j < num_cols[o]; j++) {
+      const u32 col = first_col[o] + j;
       size_t at = o == 0 ? L.op_constants + 2 * col   // constants then sigmas, contiguous
                 : o == 1 ? L.op_wires + 2 * col
                 : o == 2 ? (col < CH ? L.op_zs + 2 * col : L.op_pp + 2 * (col - CH))
                          : L.op_quot + 2 * col;
-      proof[at] = tmp[2 * j]; proof[at + 1] = tmp[2 * j + 1];
+      proof[at] = tmp[2 * (at_col[o] + j)]; proof[at + 1] = tmp[2 * (at_col[o] + j) + 1];
     }
-  }
-  if (!c->sharded() || c->bf == 0) {
-    LCP2_TRY(eval_columns(c, c->zs.coeffs.u(), CH, g_zeta, d_open, d_tab));
-    LCP2_TRY(download(ctx, proof + L.op_zs_next, d_open, 2 * CH * 8));
-  }
+  if (with_next) memcpy(proof + L.op_zs_next, tmp.data() + 2 * at_col[4], 2 * CH * 8);
   fo.phase = 1;
   return LCP2_OK;
 }
@@ -885,15 +944,13 @@ int fri_open_commit(lcp2_circuit *c, u64 *proof) {
     const u32 total_polys = ncs + W + CH * (1 + npp) + CH * Q;
     const u32 h = (p.degree_bits + 1) / 2;
     const u64 hi_count = (n >> h) + 1;
-    std::vector<u64> t;
-    gl2 cur = gl2_make(1, 0);
-    for (u32 j = 0; j < total_polys; j++) { t.push_back(cur.c0); t.push_back(cur.c1); cur = gl2_mul(cur, alpha); }
-    size_t off[8][2];
-    gl2 bases[4] = {zeta, g_zeta, gl2_inv(zeta), gl2_inv(g_zeta)};
-    for (int b = 0; b < 4; b++) ext_pow_tables(bases[b], h, hi_count, t, off[b][0], off[b][1]);
-    if (t.size() * 8 > c->tables.bytes) return ctx->fail(LCP2_E_INVALID, "internal: table workspace too small");
-    LCP2_HIP(ctx, hipMemcpyAsync(c->tables.p, t.data(), t.size() * 8, hipMemcpyHostToDevice, s));
-    LCP2_HIP(ctx, hipStreamSynchronize(s));
+    // alpha^j and the two-level power tables of zeta, g zeta and their inverses: made on the device from the two challenges in
+    // the kernel arguments (k_compose_tables; the host used to spend 0.3 ms here, then copy and synchronise)
+    const size_t per = (size_t)2 * ((1ull << h) + hi_count);
+    size_t off[4][2];
+    for (int b = 0; b < 4; b++) { off[b][0] = (size_t)2 * total_polys + b * per; off[b][1] = off[b][0] + ((size_t)2 << h); }
+    if (((size_t)2 * total_polys + 4 * per) * 8 > c->tables.bytes) return ctx->fail(LCP2_E_INVALID, "internal: table workspace too small");
+    launch_compose_tables(s, alpha.c0, alpha.c1, zeta.c0, zeta.c1, gl_root_of_unity(p.degree_bits), total_polys, h, hi_count, c->tables.u());
     ComposeArgs a{};
     for (int o = 0; o < 4; o++) { a.coeffs[o] = oracles[o]->coeffs.u(); a.ncols[o] = oracles[o]->ncols; }
     a.num_challenges = CH; a.n = n;
@@ -965,7 +1022,7 @@ int fri_open_finish(lcp2_circuit *c, u64 *proof) {
     ProfScope ps(ctx, LCP2_K_POW, 0.0);
     for (u64 start = 0; res == ~0ull; start += batch) {
       if (start >= (1ull << 44)) return ctx->fail(LCP2_E_UNSUPPORTED, "proof of work not found");
-      LCP2_HIP(ctx, hipMemsetAsync(d_res, 0xFF, 8, s));
+      { SmallWords w{}; w.v[0] = ~0ull; launch_set_words(s, d_res, w, 1); }
       a.start = start;
       launch_pow_search(s, a, batch);
       LCP2_TRY(download(ctx, &res, d_res, 8));
@@ -998,7 +1055,12 @@ int fri_open_finish(lcp2_circuit *c, u64 *proof) {
     up.push_back(mine[q] ? idx[q] - leaf0 : 0);
   }
   for (u32 q = 0; q < Qn; q++) up.push_back(p.num_fri_layers ? up[idx.size() + q] >> p.fri_arity_bits[0] : 0);  // layer-0 leaf, local
-  LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, up.data(), up.size() * 8, hipMemcpyHostToDevice, s));
+  if (ctx->pin && up.size() * 8 <= lcp2_ctx::PIN_BYTES) {  // through the pinned staging buffer (every earlier download has been waited for)
+    memcpy(ctx->pin, up.data(), up.size() * 8);
+    LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, ctx->pin, up.size() * 8, hipMemcpyHostToDevice, s));
+  } else {
+    LCP2_HIP(ctx, hipMemcpyAsync(c->q_idx.p, up.data(), up.size() * 8, hipMemcpyHostToDevice, s));
+  }
   {
     u64 *d_idx = c->q_idx.u();
     const u64 *d_idx_local = d_idx + idx.size(), *d_idx_local0 = d_idx_local + Qn;
@@ -1137,7 +1199,11 @@ extern "C" int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, c
   if (!c->rows_mode) return c->ctx->fail(LCP2_E_INVALID, "lcp2_perm_zs_rows_begin: the wires were not committed with lcp2_commit_wires_rows");
   c->perm_phase = 0;
   LCP2_TRY(perm_begin(c, (const u64 *)betas, (const u64 *)gammas));
-  if (hipStreamSynchronize(c->ctx->stream) != hipSuccess) return c->ctx->fail(LCP2_E_HIP, "lcp2_perm_zs_rows_begin: stream synchronisation failed");
+  {
+    Download d(c->ctx);
+    LCP2_TRY(queue_perm_wrap(d, c));
+    LCP2_TRY(d.wait());
+  }
   const u32 CH = c->p.num_challenges;
   memset(block_products, 0, (size_t)c->world() * CH * 8);
   for (u32 k = 0; k < CH; k++) block_products[(size_t)c->rank() * CH + k] = gl_mul(c->perm_wrap[2 * k], c->perm_wrap[2 * k + 1]);

@@ -22,6 +22,10 @@ constexpr u32 QOP_LDG = 10;      // w0 = 10 | count << 8, w1 = offset into stage
 constexpr u32 QKIND_STAGE = 5;   // operand = staging slot idx
 constexpr u32 EVAL_CHUNK = 4096;
 
+// word offsets inside lcp2_circuit::small (per-proof scalars on the device)
+constexpr size_t SMALL_BETAS = 0, SMALL_GAMMAS = 4, SMALL_ALPHAS = 8, SMALL_ALPHA_INV = 12, SMALL_PI_HASH = 16, SMALL_POW = 20,
+                 SMALL_CHECK = 21, SMALL_NONCANON = 22, SMALL_PERM_PREFIX = 24, SMALL_ALPHA_POW = 32, SMALL_GATE_SCALE = SMALL_ALPHA_POW + QUOTIENT_MAX_CH * QUOTIENT_ALPHA_POWS;
+
 struct GateDev {  // = lcp2_gate
   u32 selector_index, selector_value, group_start, group_end, code_offset, code_len, num_constraints, flags;
 };
@@ -127,5 +131,28 @@ void launch_fri_fold(hipStream_t s, const u64 *c0, const u64 *c1, u64 *o0, u64 *
 void launch_gather_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, const u64 *leaf_idx, u32 k, u64 *out);
 void launch_pow_search(hipStream_t s, const PowArgs &a, u64 count);
 void launch_fill(hipStream_t s, u64 *p, u64 n, u64 v);
+
+// ---- challenge-dependent setup on the device.  The challenges of a proof are a handful of words that the host draws from the
+// transcript; everything the kernels need that is derived from them (powers, inverses, limb tables) is computed by these small
+// kernels from the challenges passed BY VALUE in the kernel arguments: no staging vector, no host-to-device copy, no
+// synchronisation to keep a stack buffer alive.
+struct SmallWords { u64 v[16]; };
+// dst[i] = w.v[i], i < n <= 16 (betas / gammas, a flag reset, the prefix products of a row block)
+void launch_set_words(hipStream_t s, u64 *dst, const SmallWords &w, u32 n);
+// what compute_quotient_polys needs of alpha: small[SMALL_ALPHAS ..], the inverses, alpha^e (e < QUOTIENT_ALPHA_POWS), alpha^(m_g - 1) per gate,
+// the public-input hash, the reset gate-check flag, and the 22-bit limb table of alpha^e, e < QUOTIENT_TERM_POWS (QuotientArgs::alpha_limbs)
+struct QuotientSetupArgs {
+  u64 alphas[QUOTIENT_MAX_CH], pi_hash[4];
+  u32 num_challenges, num_gates;
+  const GateDev *gates;
+  u64 *small;
+  u32 *limbs;
+};
+void launch_quotient_setup(hipStream_t s, const QuotientSetupArgs &a);
+// K7a tables: tab[2 t ..] = z^t (t < 256), tab[512 + 2 k ..] = z^(chunk_len k) (k < nchunks)
+void launch_eval_tables(hipStream_t s, u64 z0, u64 z1, u32 chunk_len, u32 nchunks, u64 *tab);
+// K7b tables: alpha^j (j < total_polys) at T[0], then for each of zeta, g zeta, 1 / zeta, 1 / (g zeta) a two-level power table
+// lo[j] = b^j (j < 2^h) followed by hi[j] = b^(j << h) (j < hi_count), every entry an extension element [c0, c1]
+void launch_compose_tables(hipStream_t s, u64 a0, u64 a1, u64 z0, u64 z1, u64 g, u32 total_polys, u32 h, u64 hi_count, u64 *T);
 
 }  // namespace lcp2
