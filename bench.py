@@ -195,7 +195,7 @@ def synthetic_workload(m, ctx, sync, degree_bits, steps=3, host_witness=False):
                        "in-circuit, real copy constraints), n=2^%d rows x 135 wires, witness resident in HBM: lcp2_prove alone (no witness generation), proof verified" % degree_bits,
            "degree_bits": degree_bits, "ms_per_proof": dt / steps * 1e3, "kernels": kernel_table(prof, steps), "roofline": leaf_hash_roofline(prof["leaf_hash"], leaf_perms(degree_bits, steps))}
     hw = None
-    if host_witness and hasattr(data, "prove_host_stream"):
+    if host_witness and hasattr(data, "host_witness_benchmark"):
         try:
             del w_dev
             torch.cuda.empty_cache()

@@ -34,6 +34,7 @@ struct lcp2_ctx {
   // memory is a plain DMA that the stream orders; into pageable memory the runtime stages it and blocks
   void *pin = nullptr;
   static constexpr size_t PIN_BYTES = 1u << 20;
+  hipStream_t copy_stream = nullptr;  // uploads of staged host witnesses (lcp2_witness_stage), created at the first use
 
   int fail(int code, const std::string &msg) {
     last_error = msg;

@@ -85,6 +85,7 @@ extern "C" void lcp2_ctx_destroy(lcp2_ctx *ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_rc) (void)hipFree(ctx->d_rc);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -568,6 +569,17 @@ extern "C" int lcp2_poseidon_gate_rows(lcp2_ctx *ctx, const lcp2_poseidon_row *r
   return LCP2_OK;
 }
 
+extern "C" int lcp2_host_register(lcp2_ctx *ctx, void *host, size_t bytes) {
+  if (!ctx || !host || !bytes) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_HIP(ctx, hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return LCP2_OK;
+}
+extern "C" int lcp2_host_unregister(lcp2_ctx *ctx, void *host) {
+  if (!ctx || !host) return LCP2_E_INVALID;
+  LCP2_HIP(ctx, hipHostUnregister(host));
+  return LCP2_OK;
+}
 extern "C" int lcp2_buffer_alloc(lcp2_ctx *ctx, size_t bytes, void **dev) {
   if (!ctx || !dev) return LCP2_E_INVALID;
   LCP2_HIP(ctx, hipSetDevice(ctx->device));

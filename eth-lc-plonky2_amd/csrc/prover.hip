@@ -69,6 +69,10 @@ struct lcp2_circuit {
   bool local_quotient() const { return sharded() && p.rate_bits <= 3; }
   u64 perm_wrap[2 * QUOTIENT_MAX_CH] = {0};  // per challenge: Z before the block's last row, the last row's quotient (host)
   u64 noncanon_host = 0;   // stage_wires: a witness value was >= p (arrives with the wires cap)
+  DevBuf wit_slot[2];      // staged host witnesses (lcp2_witness_stage), [num_wires][n] each
+  hipEvent_t wit_ready[2] = {nullptr, nullptr};  // the slot's upload has finished (recorded on the context's copy stream)
+  bool wit_staged[2] = {false, false};
+  ~lcp2_circuit() { for (hipEvent_t e : wit_ready) if (e) (void)hipEventDestroy(e); }
   bool check_pending = false;  // the gate-check verdict of stage_quotient_values has not been read yet (it arrives with the quotient cap)
   uint32_t world() const { return bc ? (1u << p.rate_bits) / bc : 1; }
   uint32_t rank() const { return bc ? bf / bc : 0; }
@@ -1175,6 +1179,31 @@ extern "C" int lcp2_prove(lcp2_circuit *c, const uint64_t *wires_in_, lcp2_mem w
   lc[32] = pow_witness;
   for (u32 q = 0; q < Qn; q++) lc[33 + q] = idx[q];
   return LCP2_OK;
+}
+
+// ---- staged host witnesses: the upload of the next witness overlaps the proof in flight (include/lcp2.h)
+extern "C" int lcp2_witness_stage(lcp2_circuit *c, const uint64_t *wires, uint32_t slot) {
+  if (!c || !wires || slot > 1) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  lcp2_ctx *ctx = c->ctx;
+  if (c->sharded()) return ctx->fail(LCP2_E_INVALID, "lcp2_witness_stage: a sharded circuit takes its witness shard by shard");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)c->p.num_wires * 8 << c->p.degree_bits;
+  if (!ctx->copy_stream) LCP2_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!c->wit_ready[slot]) LCP2_HIP(ctx, hipEventCreateWithFlags(&c->wit_ready[slot], hipEventDisableTiming));
+  LCP2_HIP(ctx, c->wit_slot[slot].ensure(bytes));
+  LCP2_HIP(ctx, hipMemcpyAsync(c->wit_slot[slot].p, wires, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  LCP2_HIP(ctx, hipEventRecord(c->wit_ready[slot], ctx->copy_stream));
+  c->wit_staged[slot] = true;
+  return LCP2_OK;
+}
+extern "C" int lcp2_prove_staged(lcp2_circuit *c, uint32_t slot, const uint64_t *public_inputs, size_t num_public_inputs, uint64_t *proof, size_t proof_words) {
+  if (!c || slot > 1) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  if (!c->wit_staged[slot]) return c->ctx->fail(LCP2_E_INVALID, "lcp2_prove_staged: nothing has been staged into this slot");
+  LCP2_HIP(c->ctx, hipStreamWaitEvent(c->ctx->stream, c->wit_ready[slot], 0));  // the stream waits for the upload, the host does not
+  c->wit_staged[slot] = false;
+  return lcp2_prove(c, (const uint64_t *)c->wit_slot[slot].p, LCP2_MEM_DEVICE, public_inputs, num_public_inputs, proof, proof_words);
 }
 
 // ---- C ABI of the seams (include/lcp2.h)

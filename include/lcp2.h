@@ -305,6 +305,21 @@ int lcp2_proof_layout_of(const lcp2_params *p, lcp2_proof_layout *out);
 int lcp2_prove(lcp2_circuit *c, const uint64_t *wires, lcp2_mem wires_mem, const uint64_t *public_inputs, size_t num_public_inputs,
                uint64_t *proof, size_t proof_words);
 
+/* ---- a HOST witness without its upload on the critical path.  data.prove(pw) of a fork that runs plonky2's own generators ends up with
+ * the full witness in host memory (4.5 GB at n = 2^22); lcp2_prove(.., LCP2_MEM_HOST, ..) copies it first and proves afterwards.  For a
+ * sequence of proofs (BASELINE configs[4]: a batch of updates) the copy of witness i + 1 runs while proof i is computed:
+ *   lcp2_host_register     pins a caller-owned host buffer (a Rust Vec's storage) so that the copy is a plain DMA; optional, but a
+ *                          pageable buffer is staged by the runtime and lcp2_witness_stage then blocks for the whole copy
+ *   lcp2_witness_stage     starts the upload of `wires` ([num_wires][n], any u64 values) into staging slot 0 or 1 of the circuit, on a
+ *                          copy stream of the context; returns at once.  The host buffer must stay unchanged until the
+ *                          lcp2_prove_staged of that slot has returned.  A slot must not be staged again before its proof returned.
+ *   lcp2_prove_staged      lcp2_prove on the slot's device copy (the context's stream waits for the upload, the host does not)
+ * The two slots are allocated at the first use (2 x num_wires x n x 8 bytes of HBM). */
+int lcp2_host_register(lcp2_ctx *ctx, void *host, size_t bytes);
+int lcp2_host_unregister(lcp2_ctx *ctx, void *host);
+int lcp2_witness_stage(lcp2_circuit *c, const uint64_t *wires, uint32_t slot);
+int lcp2_prove_staged(lcp2_circuit *c, uint32_t slot, const uint64_t *public_inputs, size_t num_public_inputs, uint64_t *proof, size_t proof_words);
+
 /* ---- the seams inside data.prove() a plonky2 fork binds one by one; lcp2_prove is exactly their
  * composition under the Fiat-Shamir transcript, and the caller keeps its own Challenger in between.  The commitments
  * stay on the device inside the circuit handle; the calls must come in this order (LCP2_E_INVALID otherwise).

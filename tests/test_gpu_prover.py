@@ -104,6 +104,41 @@ def test_light_client_step_in_process(gpu_ctx):
     ssz.close()
 
 
+def test_staged_host_witnesses(gpu_ctx, oracle):
+    """lcp2_witness_stage / lcp2_prove_staged: two host witnesses of one circuit uploaded on the copy stream into the two staging slots
+    (one from pinned, one from pageable memory) while proofs run; every proof equals the oracle's proof of the same witness; a slot
+    that was not staged is refused"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(12, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=77)
+    other = m.circuit.tag_witness(wires.copy(), 5)
+    oc = oracle_lib.OracleCircuit(oracle, circ)
+    want = [oc.prove(wires, pis), oc.prove(other, pis)]
+    assert not (want[0] == want[1]).all()
+    data = m.CircuitData.build(gpu_ctx, circ)
+    with pytest.raises(m.Lcp2Error):
+        data.prove_staged(0, pis)
+    lib = gpu_ctx.lib
+    import ctypes
+    assert lib.lcp2_host_register(gpu_ctx.handle, wires.ctypes.data_as(ctypes.c_void_p), wires.nbytes) == 0
+    try:
+        data.stage_witness(wires, 0)
+        for i in range(4):
+            nxt = (i + 1) % 2
+            data.stage_witness(other if nxt else wires, nxt)   # the next witness goes up while this proof runs
+            got = data.prove_staged(i % 2, pis)
+            assert (got == want[i % 2]).all(), i
+        got = data.prove_staged(0, pis)  # staged in the last iteration
+        assert (got == want[0]).all()
+        with pytest.raises(m.Lcp2Error):
+            data.prove_staged(0, pis)    # a slot is consumed by its proof
+    finally:
+        gpu_ctx.sync()
+        lib.lcp2_host_unregister(gpu_ctx.handle, wires.ctypes.data_as(ctypes.c_void_p))
+    data.close()
+    oc.close()
+
+
 def test_workspace_reuse_and_device_resident_witness(gpu_ctx, oracle):
     import torch
     import eth_lc_plonky2_amd as m
