@@ -370,16 +370,22 @@ struct Values {
   std::vector<F> val;
   std::vector<uint8_t> has;
   explicit Values(const CircuitData::Impl *dd) : d(dd), val(dd->parent.size(), 0), has(dd->parent.size(), 0) {}
-  // The generators of one phase may run on several threads (run_host_phase): a value is published by the release store of its
-  // flag and read after an acquire load of it.  Two generators never produce the same class with different values in a
-  // satisfiable witness; when they do, one of them sees the other's value and throws, as on one thread.
-  bool known(uint32_t r) const { return __atomic_load_n(&has[r], __ATOMIC_ACQUIRE) != 0; }
+  // The generators of one phase may run on several threads (run_host_phase, LCP2_HOST_LANES > 1).  A slot goes 0 (empty) -> 2 (claimed:
+  // one writer is storing the value) -> 1 (published); the claim is a compare-and-swap, so exactly one generator writes val[r] and
+  // every other one - on any lane - compares with the published value: two generators that disagree about a connected class are
+  // always reported, never a torn or lost write.
+  bool known(uint32_t r) const { return __atomic_load_n(&has[r], __ATOMIC_ACQUIRE) == 1; }
   void set(uint32_t var, F v, const char *what) {
     uint32_t r = d->find(var);
-    if (known(r) && val[r] != v)
+    uint8_t expected = 0;
+    if (__atomic_compare_exchange_n(&has[r], &expected, (uint8_t)2, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+      val[r] = v;
+      __atomic_store_n(&has[r], (uint8_t)1, __ATOMIC_RELEASE);
+      return;
+    }
+    while (__atomic_load_n(&has[r], __ATOMIC_ACQUIRE) != 1) {}  // another lane is between its claim and its store: a few cycles
+    if (val[r] != v)
       throw UnsatisfiedError(std::string("witness conflict on a connected target (") + what + "): " + std::to_string(val[r]) + " vs " + std::to_string(v));
-    val[r] = v;
-    __atomic_store_n(&has[r], (uint8_t)1, __ATOMIC_RELEASE);
   }
   F get(uint32_t var, const char *what) const {
     uint32_t r = d->find(var);
@@ -661,8 +667,8 @@ static void run_host_phase(const CircuitData::Impl *d, const HostLanes &L, std::
       if (epoch) epoch->fetch_add(1, std::memory_order_release);
       progress = true;
     }
-    st.visits += mine.size();  // (racy across lanes: a statistic)
-    st.sweeps++;
+    __atomic_fetch_add(&st.visits, mine.size(), __ATOMIC_RELAXED);  // shared by the lanes
+    __atomic_fetch_add(&st.sweeps, (size_t)1, __ATOMIC_RELAXED);
     mine.swap(waiting);
     return progress;
   };

@@ -314,6 +314,9 @@ class TorchComm:
     # Message sizes beyond these go in pieces: collectives with more than 1 GiB per peer are the rare case in RCCL's use (and its
     # one-rank all-to-all demonstrably mishandles them, tools/rccl_a2a_probe.py); at 8 ranks and n = 2^22 nothing is split
     A2A_WORDS_PER_PAIR = 1 << 26     # 512 MiB per pair
+    A2A_WORDS_PER_CALL = 1 << 27     # 1 GiB per call and rank: the one measured defect (profiles/r03_rccl_a2a_probe.log, world 1) is keyed on the
+                                     # TOTAL size of a call; at n = 2^22 over 4 ranks an unsplit call would carry 4 x 285 MB.  Both bounds are guesses
+                                     # about multi-rank RCCL (it has not run here): the proof's verification stays the acceptance signal
     GATHER_WORDS_PER_RANK = 1 << 27  # 1 GiB per rank
 
     def __init__(self, dist, device=None, ctx=None, staged=None):
@@ -385,12 +388,13 @@ class TorchComm:
             tmp = torch.empty_like(recv)
             self.dist.all_to_all_single(tmp, send.clone())
             recv.copy_(tmp)
-        elif k <= self.A2A_WORDS_PER_PAIR:
+        elif k <= self.A2A_WORDS_PER_PAIR and world * k <= self.A2A_WORDS_PER_CALL:
             self.dist.all_to_all_single(recv, send)
-        else:  # large messages in pieces, each through a packed staging pair
+        else:  # large messages in pieces, each through a packed staging pair; a piece is bounded per pair AND per call
             import torch
-            for off in range(0, k, self.A2A_WORDS_PER_PAIR):
-                end = min(off + self.A2A_WORDS_PER_PAIR, k)
+            step = max(1, min(self.A2A_WORDS_PER_PAIR, self.A2A_WORDS_PER_CALL // world))
+            for off in range(0, k, step):
+                end = min(off + step, k)
                 packed = torch.cat([send[d * k + off:d * k + end] for d in range(world)])
                 got = torch.empty_like(packed)
                 self.dist.all_to_all_single(got, packed)

@@ -408,7 +408,10 @@ static bool generate_with(const Program &P, int k, Result &R, bool greedy_all) {
   }
   // occupancy the kernel asks for (k_q_gen's launch bounds): 2 VGPRs per live value, 24 for the column sums, 16 for the loads in
   // flight, ~25 of temporaries and addresses; 512 VGPRs per SIMD lane
-  R.waves = P.waves ? P.waves : peak <= 24 ? 4 : peak <= 50 ? 3 : 2;
+  {  // 2 VGPRs per live value, two windows of loads in flight, 24 for the column sums, ~36 of temporaries and addresses; 512 per SIMD lane
+    const size_t vg = 2 * peak + 4 * WINDOW_LOADS + 60;  // (measured: 16-load windows are no faster than 8 for the plonky2_u32 gates, profiles/r04_k6_experiments.md)
+    R.waves = P.waves ? P.waves : vg <= 140 ? 4 : vg <= 192 ? 3 : 2;
+  }
   // ---- emission
   appendf(o, "// %s: %zu instructions, %u constraints, %zu wires and gate constants; at most %zu 64-bit values live in this schedule\n",
           P.name.c_str(), P.code.size() / 2, P.m, all_loads.size(), peak);
@@ -506,6 +509,7 @@ static bool read_dump(const char *path, Dump &D) {
       for (auto &w : P.code) { unsigned x; if (fscanf(f, "%x", &x) != 1) return false; w = x; }
       P.imm = &D.imm_tables.back();
       P.rewrite = true;
+      if (const char *w = getenv("GEN_WINDOW")) P.window_loads = (size_t)atoi(w);  // experiments only: the committed headers are made without it
       P.group = set_name;
       D.programs.push_back(P);
       continue;
