@@ -104,6 +104,33 @@ def test_light_client_step_in_process(gpu_ctx):
     ssz.close()
 
 
+def test_host_generator_lanes_give_the_same_proof(gpu_ctx):
+    """LCP2_HOST_LANES > 1 spreads the host generators of a witness generation (here: the recursive verifier's PoseidonGate chains of the
+    light-client circuit with the stand-in inner proof) over threads; value slots are claimed by compare-and-swap (host/builder.cpp
+    Values::set).  The proof must be the one a single lane gives, word for word, proof after proof."""
+    import os
+    import eth_lc_plonky2_amd as m
+    prev, cur = m.light_client.reference_updates()
+    proofs = {}
+    old = os.environ.get("LCP2_HOST_LANES")
+    try:
+        for lanes in ("1", "4"):
+            os.environ["LCP2_HOST_LANES"] = lanes  # read when the first proof of a circuit plans its lanes
+            step = m.light_client.LightClientStep(gpu_ctx, prev, cur, flags=m.light_client.BLS_PROOF_STAND_IN)
+            got = [step.prove() for _ in range(3)]
+            for proof, pis in got:
+                step.verify(proof, pis)
+                assert (proof == got[0][0]).all() and (pis == step.expected_public_inputs).all()
+            proofs[lanes] = got[0][0]
+            step.close()
+    finally:
+        if old is None:
+            os.environ.pop("LCP2_HOST_LANES", None)
+        else:
+            os.environ["LCP2_HOST_LANES"] = old
+    assert (proofs["1"] == proofs["4"]).all()
+
+
 def test_staged_host_witnesses(gpu_ctx, oracle):
     """lcp2_witness_stage / lcp2_prove_staged: two host witnesses of one circuit uploaded on the copy stream into the two staging slots
     (one from pinned, one from pageable memory) while proofs run; every proof equals the oracle's proof of the same witness; a slot

@@ -542,6 +542,7 @@ int main(int argc, char **argv) {
       P.imm = &gs.imm;
       P.window_loads = window_loads_of[t];
       P.waves = waves_of[t++];
+      if (getenv("GEN_SHA_REWRITE")) { P.rewrite = true; P.waves = 0; if (!P.window_loads) P.window_loads = 8; }  // experiments only
       P.group = "sha";
       programs.push_back(P);
     }
