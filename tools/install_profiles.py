@@ -72,3 +72,25 @@ with open(f"{p}/{tag}_sq_counters.csv", "w") as f:
             k, len(v["dur_ms"]), d, waves, max(v["vgpr"]), iv / waves, tot("SQ_INSTS_SALU") / waves, tot("SQ_INSTS_LDS") / waves,
             tot("SQ_WAIT_ANY") / max(tot("SQ_WAVE_CYCLES"), 1), gui / 8 / (d * 1e-3) / 1e9 if d else 0, (gui / 8) / (iv / 1024) if iv else 0))
 print(open(f"{p}/{tag}_sq_counters.csv").read())
+# ---- round 4 additions: the reference gate set, K6 summaries, idle time, the oracle's scaling sample
+def have(path):
+    return os.path.exists(path)
+
+
+if have(f"{src}/mixkt/mixkt_kernel_stats.csv"):
+    shutil.copy(f"{src}/mixkt/mixkt_kernel_stats.csv", f"{p}/{tag}_reference_mix_kernel_stats.csv")
+    subprocess.run([sys.executable, f"{root}/tools/k6_profile_summary.py", f"{src}/mixkt/mixkt_kernel_stats.csv", f"{src}/mixfetch/mixfetch_counter_collection.csv", "2", "22", "5",
+                    f"{p}/{tag}_reference_mix_k6.json", f"{p}/{tag}_reference_mix_fetch_size.csv"], check=True, stdout=subprocess.DEVNULL)
+    for name in ("mix_native", "mix_interpreted"):
+        if have(f"{src}/{name}.json"):
+            open(f"{p}/{tag}_reference_{name}.json", "w").write([l for l in open(f"{src}/{name}.json") if l.startswith("{")][-1])
+# K6 of the headline circuit (the own SHA-256 gates) from the bench's own two passes: kernel stats + FETCH_SIZE
+subprocess.run([sys.executable, f"{root}/tools/k6_profile_summary.py", f"{src}/kt/kt_kernel_stats.csv", f"{src}/fetch/fetch_counter_collection.csv", "1", "22", "5",
+                f"{p}/{tag}_real_gadget_k6.json"], check=True, stdout=subprocess.DEVNULL)
+for name, trace in (("headline", f"{src}/kt/kt_kernel_trace.csv"), ("lc_step", f"{src}/lc/lc_kernel_trace.csv"), ("reference_mix", f"{src}/mixkt/mixkt_kernel_trace.csv")):
+    if have(trace):
+        subprocess.run([sys.executable, f"{root}/tools/trace_gaps.py", trace, f"{p}/{tag}_gaps_{name}.json"], check=True, stdout=subprocess.DEVNULL)
+if have(f"{src}/cpu_baseline_scaling.json"):
+    open(f"{p}/{tag}_cpu_baseline_scaling.json", "w").write([l for l in open(f"{src}/cpu_baseline_scaling.json") if l.startswith("{")][-1])
+if have(f"{src}/lc.log"):
+    shutil.copy(f"{src}/lc.log", f"{p}/{tag}_lc_step.log")
