@@ -26,7 +26,8 @@ json_line(f"{src}/bench_under_rocprof.json", f"{p}/{tag}_bench_under_rocprof.jso
 json_line(f"{src}/bench_under_pmc_fetch.json", f"{p}/{tag}_bench_under_pmc_fetch.json")
 shutil.copy(f"{src}/kt/kt_kernel_stats.csv", f"{p}/{tag}_full_proof_kernel_stats.csv")
 shutil.copy(f"{src}/lc/lc_kernel_stats.csv", f"{p}/{tag}_lc_step_kernel_stats.csv")
-shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
+if os.path.exists(f"{src}/ubench.txt"):
+    shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
 if os.path.exists(f"{src}/sharded_rehearsal.log"):
     shutil.copy(f"{src}/sharded_rehearsal.log", f"{p}/{tag}_sharded_rehearsal.log")
 if os.path.exists(f"{src}/bench_force_sharded.json"):
