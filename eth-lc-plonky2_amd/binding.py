@@ -103,6 +103,7 @@ def load_library():
         "lcp2_ctx_create_ex": (c.c_int, [c.c_int, c.c_void_p, c.c_uint32, c.POINTER(c.c_void_p)]),
         "lcp2_ctx_destroy": (None, [c.c_void_p]),
         "lcp2_ctx_sync": (c.c_int, [c.c_void_p]),
+        "lcp2_ctx_stream": (c.c_void_p, [c.c_void_p]),
         "lcp2_last_error": (c.c_char_p, [c.c_void_p]),
         "lcp2_poseidon_permute_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]),
         "lcp2_merkle_cap": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_uint32, c.c_int, c.c_void_p]),
@@ -112,6 +113,9 @@ def load_library():
         "lcp2_sha256_witness": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint32, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64, c.c_void_p]),
         "lcp2_scatter_cells": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64]),
         "lcp2_poseidon_gate_rows": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_uint64]),
+        "lcp2_commit_wires_rows_begin": (c.c_int, [c.c_void_p, c.c_void_p]),
+        "lcp2_commit_wires_chunk": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32]),
+        "lcp2_commit_wires_rows_finish": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_host_register": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t]),
         "lcp2_host_unregister": (c.c_int, [c.c_void_p, c.c_void_p]),
         "lcp2_witness_stage": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint32]),
@@ -268,6 +272,10 @@ class Context:
 
     def sync(self):
         self._check(self.lib.lcp2_ctx_sync(self.handle))
+
+    def stream_ptr(self):
+        """the hipStream_t the context runs on (an integer; torch.cuda.ExternalStream(ptr) wraps it)"""
+        return self.lib.lcp2_ctx_stream(self.handle) or 0
 
     # ---- primitives on host numpy arrays
     def poseidon_permute_batch(self, states):
@@ -636,6 +644,17 @@ class CircuitData:
     def commit_wires_rows(self, rows_ptr, coeffs_ptr):
         cap = self._cap()
         self._check(self.lib.lcp2_commit_wires_rows(self.handle, ctypes.c_void_p(rows_ptr), ctypes.c_void_p(coeffs_ptr), _ptr(cap)))
+        return cap
+
+    def commit_wires_rows_begin(self, rows_ptr):
+        self._check(self.lib.lcp2_commit_wires_rows_begin(self.handle, ctypes.c_void_p(rows_ptr)))
+
+    def commit_wires_chunk(self, coeffs_ptr, first_col, ncols):
+        self._check(self.lib.lcp2_commit_wires_chunk(self.handle, ctypes.c_void_p(coeffs_ptr), first_col, ncols))
+
+    def commit_wires_rows_finish(self):
+        cap = self._cap()
+        self._check(self.lib.lcp2_commit_wires_rows_finish(self.handle, _ptr(cap)))
         return cap
 
     def perm_zs_rows_begin(self, betas, gammas, world):

@@ -93,6 +93,10 @@ void launch_poseidon_permute_batch(hipStream_t s, const u64 *in, u64 *out, size_
 void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col_stride, u32 leaf_len, u64 nleaves,
                         u64 *digests, const u64 *rc);
 // leaves of `arity` extension elements taken from two planes (c0, c1): leaf k = flatten(e[arity*k .. arity*(k+1)))
+// the sponge of k_hash_leaves over `ncols` columns starting at `data` (element c of leaf i at data[c * col_stride + i]), state[12][nleaves]
+// carried between launches: first = start from the zero state, last = write the digests instead of the state
+void launch_hash_leaves_absorb(hipStream_t s, const u64 *data, u64 col_stride, u32 ncols, u64 nleaves, u64 *state, bool first, bool last,
+                               u64 *digests, const u64 *rc);
 void launch_hash_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, u64 nleaves, u64 *digests, const u64 *rc);
 void launch_merkle_level(hipStream_t s, const u64 *children, u64 *parents, u64 nparents, const u64 *rc);
 void launch_ntt_pass(hipStream_t s, bool inverse, const NttPassParams &p, u32 wgs, u32 cols, u32 nz);
@@ -160,4 +164,7 @@ int commit_values_dev(lcp2_ctx *ctx, const u64 *d_vals, size_t ncols, uint32_t l
 int commit_coeffs_dev(lcp2_ctx *ctx, const u64 *d_coeffs, size_t ncols, uint32_t log_n, uint32_t rate_bits,
                       uint32_t cap_height, lcp2_oracle *o, bool take_copy);
 int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o);
+// its two halves for a commitment that hashes its leaves chunk by chunk: the digest storage and level offsets, then the levels above the leaves
+int merkle_alloc_dev(lcp2_ctx *ctx, lcp2_oracle *o);
+int merkle_levels_dev(lcp2_ctx *ctx, lcp2_oracle *o);
 }  // namespace lcp2

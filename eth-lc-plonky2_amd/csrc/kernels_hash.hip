@@ -61,6 +61,39 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves(const u64 *__restr
   d[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// The same sponge over a CHUNK of the columns of a leaf, its state kept between launches (state[j][leaf], column-major): a sharded proof
+// absorbs the coefficient chunks that have arrived while the next ones are still crossing the fabric (lcp2_commit_wires_chunk).  The
+// chunks come in column order, each but the last a multiple of 8 columns, so the permutations fall where k_hash_leaves puts them.
+__global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves_absorb(const u64 *__restrict__ data, u64 col_stride, u32 ncols, u64 nleaves,
+                                                                      u64 *__restrict__ state, u32 first, u32 last, u64 *__restrict__ digests,
+                                                                      const u64 *__restrict__ rc) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nleaves) return;
+  const u64 *row = data + i;
+  u64 s[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) s[j] = first ? 0 : state[(u64)j * nleaves + i];
+  for (u32 c0 = 0; c0 < ncols; c0 += 8) {
+    if (c0 + 8 <= ncols) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) s[j] = gl_canon(row[(u64)(c0 + j) * col_stride]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (c0 + j < ncols) s[j] = gl_canon(row[(u64)(c0 + j) * col_stride]);
+    }
+    pos_permute(s, rc);
+  }
+  if (last) {
+    ulonglong2 *d = (ulonglong2 *)(digests + 4 * i);
+    d[0] = make_ulonglong2(s[0], s[1]);
+    d[1] = make_ulonglong2(s[2], s[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; j++) state[(u64)j * nleaves + i] = s[j];
+  }
+}
+
 __global__ __launch_bounds__(HASH_THREADS) void k_hash_ext_leaves(const u64 *__restrict__ p0, const u64 *__restrict__ p1, u32 arity,
                                                                    u64 nleaves, u64 *__restrict__ digests,
                                                                    const u64 *__restrict__ rc) {
@@ -233,6 +266,11 @@ void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col
                         const u64 *rc) {
   hipLaunchKernelGGL(k_hash_leaves, dim3(blocks_for(nleaves, HASH_THREADS)), dim3(HASH_THREADS), 0, s, data, leaf_stride, col_stride,
                      leaf_len, nleaves, digests, rc);
+}
+void launch_hash_leaves_absorb(hipStream_t s, const u64 *data, u64 col_stride, u32 ncols, u64 nleaves, u64 *state, bool first, bool last,
+                               u64 *digests, const u64 *rc) {
+  hipLaunchKernelGGL(k_hash_leaves_absorb, dim3(blocks_for(nleaves, HASH_THREADS)), dim3(HASH_THREADS), 0, s, data, col_stride, ncols, nleaves,
+                     state, first ? 1u : 0u, last ? 1u : 0u, digests, rc);
 }
 void launch_hash_ext_leaves(hipStream_t s, const u64 *p0, const u64 *p1, u32 arity, u64 nleaves, u64 *digests, const u64 *rc) {
   if (nleaves <= POS_COOP_MAX_NODES && 2 * arity > 4) {

@@ -75,6 +75,8 @@ extern "C" int lcp2_ctx_create_ex(int device, void *stream, uint32_t flags, lcp2
   return LCP2_OK;
 }
 
+extern "C" void *lcp2_ctx_stream(lcp2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 extern "C" void lcp2_ctx_destroy(lcp2_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -213,7 +215,7 @@ extern "C" int lcp2_poseidon_permute_batch(lcp2_ctx *ctx, const uint64_t *in, ui
 
 namespace lcp2 {
 // digests: level 0 at offset 0; fills o->level_off and all levels up to the cap
-int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
+int merkle_alloc_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
   const u64 N = o->nleaves();
   const u32 nlev = o->nlevels();
   o->level_off.resize(nlev);
@@ -222,17 +224,25 @@ int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
   LCP2_HIP(ctx, o->digests.ensure(total * 4 * sizeof(u64)));
   LCP2_HIP(ctx, o->d_level_off.ensure(nlev * sizeof(u64)));
   LCP2_HIP(ctx, hipMemcpyAsync(o->d_level_off.p, o->level_off.data(), nlev * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+  return LCP2_OK;
+}
+int merkle_levels_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
+  const u64 N = o->nleaves();
+  const u32 nlev = o->nlevels();
+  ProfScope ps(ctx, LCP2_K_MERKLE, 96.0 * (double)(N - (N >> (nlev - 1))));
+  for (u32 l = 1; l < nlev; l++)
+    launch_merkle_level(ctx->stream, o->digests.u() + 4 * o->level_off[l - 1], o->digests.u() + 4 * o->level_off[l], N >> l, ctx->d_rc);
+  LCP2_HIP(ctx, hipGetLastError());
+  return LCP2_OK;
+}
+int build_merkle_dev(lcp2_ctx *ctx, lcp2_oracle *o) {
+  const u64 N = o->nleaves();
+  LCP2_TRY(merkle_alloc_dev(ctx, o));
   {
     ProfScope ps(ctx, LCP2_K_LEAF_HASH, (double)N * (8.0 * o->ncols + 32.0));
     launch_hash_leaves(ctx->stream, o->lde.u(), 1, N, o->ncols, N, o->digests.u(), ctx->d_rc);
   }
-  {
-    ProfScope ps(ctx, LCP2_K_MERKLE, 96.0 * (double)(N - (N >> (nlev - 1))));
-    for (u32 l = 1; l < nlev; l++)
-      launch_merkle_level(ctx->stream, o->digests.u() + 4 * o->level_off[l - 1], o->digests.u() + 4 * o->level_off[l], N >> l, ctx->d_rc);
-  }
-  LCP2_HIP(ctx, hipGetLastError());
-  return LCP2_OK;
+  return merkle_levels_dev(ctx, o);
 }
 
 static int lde_and_merkle(lcp2_ctx *ctx, lcp2_oracle *o) {

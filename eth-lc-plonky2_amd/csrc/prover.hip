@@ -69,6 +69,8 @@ struct lcp2_circuit {
   bool local_quotient() const { return sharded() && p.rate_bits <= 3; }
   u64 perm_wrap[2 * QUOTIENT_MAX_CH] = {0};  // per challenge: Z before the block's last row, the last row's quotient (host)
   u64 noncanon_host = 0;   // stage_wires: a witness value was >= p (arrives with the wires cap)
+  DevBuf leaf_state;       // chunked commitment of the wires (lcp2_commit_wires_chunk): the sponge state of every local leaf, [12][leaves]
+  int chunk_next = -1;     // the column the next chunk must start at; -1: no chunked commitment in progress
   DevBuf wit_slot[2];      // staged host witnesses (lcp2_witness_stage), [num_wires][n] each
   hipEvent_t wit_ready[2] = {nullptr, nullptr};  // the slot's upload has finished (recorded on the context's copy stream)
   bool wit_staged[2] = {false, false};
@@ -1221,6 +1223,82 @@ extern "C" int lcp2_commit_wires_rows(lcp2_circuit *c, const uint64_t *wire_rows
   if (!c || !wire_rows || !coeffs || !cap) return LCP2_E_INVALID;
   if (!c->ctx) return LCP2_E_NODEVICE;
   return stage_wires(c, (const u64 *)wire_rows, LCP2_MEM_DEVICE, (const u64 *)coeffs, (u64 *)cap, true);
+}
+// ---- the chunked form of lcp2_commit_wires_rows (include/lcp2.h)
+extern "C" int lcp2_commit_wires_rows_begin(lcp2_circuit *c, const uint64_t *wire_rows) {
+  if (!c || !wire_rows) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  lcp2_ctx *ctx = c->ctx;
+  const lcp2_params &p = c->p;
+  const u64 n = 1ull << p.degree_bits;
+  if (!c->sharded() || n < c->world() || p.num_wires <= 4)
+    return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_rows_begin: needs a sharded circuit with at least one row per rank and more than 4 wires");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  c->rows_mode = true; c->perm_phase = 0; c->fo.phase = 0; c->stage = lcp2_circuit::ST_NONE;
+  unsigned long long *d_flag = (unsigned long long *)(c->small.u() + SMALL_NONCANON);
+  launch_set_words(s, c->small.u() + SMALL_NONCANON, SmallWords{}, 1);
+  launch_canon_copy(s, (const u64 *)wire_rows, nullptr, (u64)p.num_wires * c->rows(), d_flag);
+  if (!c->cs_rows_ready) {  // the gate check reads the constants with the stride of the wires
+    const u64 R = c->rows();
+    LCP2_HIP(ctx, c->cs_rows.ensure((size_t)p.num_constants * R * 8));
+    launch_copy_2d(s, c->cs_rows.u(), R, c->cs_values.u() + c->row0(), n, R, p.num_constants);
+    c->cs_rows_ready = true;
+  }
+  lcp2_oracle *o = &c->wires;
+  o->ctx = ctx; o->ncols = p.num_wires; o->log_n = p.degree_bits; o->rate_bits = p.rate_bits; o->cap_height = p.cap_height;
+  LCP2_HIP(ctx, o->coeffs.ensure((size_t)p.num_wires * n * 8));
+  LCP2_HIP(ctx, o->lde.ensure((size_t)p.num_wires * o->nleaves() * 8));
+  LCP2_TRY(merkle_alloc_dev(ctx, o));
+  LCP2_HIP(ctx, c->leaf_state.ensure((size_t)12 * o->nleaves() * 8));
+  c->d_wires_cur = (const u64 *)wire_rows;
+  c->chunk_next = 0;
+  return LCP2_OK;
+}
+extern "C" int lcp2_commit_wires_chunk(lcp2_circuit *c, const uint64_t *coeffs, uint32_t first_col, uint32_t ncols) {
+  if (!c || !coeffs) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  lcp2_ctx *ctx = c->ctx;
+  const lcp2_params &p = c->p;
+  if (c->chunk_next < 0 || (int)first_col != c->chunk_next) return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_chunk: chunks come in column order after lcp2_commit_wires_rows_begin");
+  if (ncols == 0 || first_col % 8 || first_col + ncols > p.num_wires || (ncols % 8 && first_col + ncols != p.num_wires))
+    return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_chunk: a chunk starts at a multiple of 8 columns and is a multiple of 8 long unless it is the last");
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  lcp2_oracle *o = &c->wires;
+  const u64 n = 1ull << p.degree_bits, N = o->nleaves();
+  hipStream_t s = ctx->stream;
+  u64 *dst = o->coeffs.u() + (size_t)first_col * n;
+  if ((const u64 *)coeffs != dst) LCP2_HIP(ctx, hipMemcpyAsync(dst, coeffs, (size_t)ncols * n * 8, hipMemcpyDeviceToDevice, s));
+  DeviceNttBackend be{ctx};
+  NttHost<DeviceNttBackend> ntt(be);
+  {
+    ProfScope ps(ctx, LCP2_K_LDE, (double)ncols * (8.0 * n + 8.0 * N));
+    ntt.forward(dst, n, o->lde.u() + (size_t)first_col * N, N, p.degree_bits, ncols, GL_GENERATOR, p.rate_bits, o->block_first, o->block_count);
+  }
+  if (be.status) return be.status;
+  const bool last = first_col + ncols == p.num_wires;
+  {
+    ProfScope ps(ctx, LCP2_K_LEAF_HASH, (double)N * (8.0 * ncols + (last ? 32.0 : 0.0)));
+    launch_hash_leaves_absorb(s, o->lde.u() + (size_t)first_col * N, N, ncols, N, c->leaf_state.u(), first_col == 0, last, o->digests.u(), ctx->d_rc);
+  }
+  LCP2_HIP(ctx, hipGetLastError());
+  c->chunk_next = (int)(first_col + ncols);
+  return LCP2_OK;
+}
+extern "C" int lcp2_commit_wires_rows_finish(lcp2_circuit *c, uint64_t *cap) {
+  if (!c || !cap) return LCP2_E_INVALID;
+  if (!c->ctx) return LCP2_E_NODEVICE;
+  lcp2_ctx *ctx = c->ctx;
+  if (c->chunk_next != (int)c->p.num_wires) return ctx->fail(LCP2_E_INVALID, "lcp2_commit_wires_rows_finish: not every column has been absorbed");
+  c->chunk_next = -1;
+  LCP2_HIP(ctx, hipSetDevice(ctx->device));
+  LCP2_TRY(merkle_levels_dev(ctx, &c->wires));
+  Download d(ctx);
+  LCP2_TRY(queue_cap(d, c, c->wires, (u64 *)cap));
+  LCP2_TRY(d.add(&c->noncanon_host, c->small.u() + SMALL_NONCANON, 8));
+  LCP2_TRY(d.wait());
+  c->stage = lcp2_circuit::ST_WIRES;
+  return LCP2_OK;
 }
 extern "C" int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *block_products) {
   if (!c || !betas || !gammas || !block_products) return LCP2_E_INVALID;

@@ -27,6 +27,16 @@ def column_shards(ncols, world_size):
     return out
 
 
+def chunk_columns(num_wires, rank, world_size):
+    """Chunked coefficient exchange (ShardedProver.prove_steps(..., chunked=True)): chunk j is the columns [8 j, 8 j + 8) - what one
+    permutation of a leaf's sponge absorbs - and inside a chunk rank r owns the 8 / world columns [8 j + r k, 8 j + (r + 1) k): every
+    chunk is an in-place all-gather with one contiguous piece per rank.  Returns the columns rank `rank` brings, in increasing order."""
+    if world_size not in (1, 2, 4, 8):
+        raise ValueError("chunked exchange: 1, 2, 4 or 8 ranks")
+    k = 8 // world_size
+    return [c for c in range(num_wires) if (c % 8) // k == rank]
+
+
 def block_range(rank, world_size, rate_bits=3):
     nblocks = 1 << rate_bits
     if world_size < 1 or nblocks % world_size or (world_size & (world_size - 1)):
@@ -164,10 +174,12 @@ class ShardedProver:
                     self.ctx.buffer_copy(buf + 8 * (s0 + col) * run, buf + 8 * (r * most + col) * run, run)
 
     # the proof as a generator of exchange points, so that a test can interleave several ranks in one process
-    def prove_steps(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False):
+    def prove_steps(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False, chunked=False):
         """wires: the whole witness [num_wires][n] (numpy, or a device pointer with mem=MEM_DEVICE); with sharded_columns=True
         only this rank's columns [column_shard()][n].  row_exchange (with sharded_columns): the values cross the ranks as row
-        blocks (all-to-all) instead of whole columns (all-gather), see the class comment."""
+        blocks (all-to-all) instead of whole columns (all-gather), see the class comment.  chunked (with row_exchange): this rank
+        brings the columns chunk_columns(num_wires, rank, world) and the coefficient exchange is overlapped with the commitment,
+        chunk by chunk (_commit_wires_chunked)."""
         b, d, p, ctx = self.b, self.data, self.circ.params, self.ctx
         capw = 4 << p.cap_height
         n = 1 << p.degree_bits
@@ -179,7 +191,11 @@ class ShardedProver:
         ch.observe(pi_hash)
         if row_exchange and not (sharded_columns and n >= self.world):
             raise ValueError("row_exchange needs the column-sharded arrival and at least one row per rank")
-        if sharded_columns:
+        if chunked and not row_exchange:
+            raise ValueError("the chunked coefficient exchange belongs to the row exchange form")
+        if chunked:
+            share = yield from self._commit_wires_chunked(wires, mem)
+        elif sharded_columns:
             shards = column_shards(p.num_wires, self.world)
             most = max(e - s for s, e in shards)
             first, end = shards[self.rank]
@@ -270,8 +286,56 @@ class ShardedProver:
         self.proof = proof
         return
 
-    def prove(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False):
-        steps = self.prove_steps(wires, public_inputs, mem, sharded_columns, row_exchange)
+    def _commit_wires_chunked(self, wires, mem):
+        """The wires commitment of the row exchange form with the 4 GB coefficient all-gather OVERLAPPED: the sponge of a leaf absorbs the
+        columns in order, 8 per permutation, so chunk j (columns 8 j .. 8 j + 7, one or a few per rank) is gathered - asynchronously, on the
+        communicator's own stream - while chunk j - 1 runs its coset LDE and is absorbed into the persistent leaf states
+        (lcp2_commit_wires_chunk).  Only the first chunk's exchange is exposed."""
+        b, d, p, ctx = self.b, self.data, self.circ.params, self.ctx
+        n, W, world, rank = 1 << p.degree_bits, p.num_wires, self.world, self.rank
+        k, nch = 8 // world, -(-W // 8)
+        cols = chunk_columns(W, rank, world)
+        most, rows = nch * k, n // world
+        if getattr(self, "_chunk_bufs", None) is None:
+            # own values [most][n], own coefficients [most][n], row blocks to send / received [world][most][rows], the rows in column
+            # order [8 nch][rows], the coefficient columns in column order [8 nch][n]
+            self._chunk_bufs = [ctx.buffer_alloc(most * n), ctx.buffer_alloc(most * n), ctx.buffer_alloc(world * most * rows),
+                                ctx.buffer_alloc(world * most * rows), ctx.buffer_alloc(8 * nch * rows), ctx.buffer_alloc(8 * nch * n)]
+        own, cown, send, recv, rowsbuf, cbase = self._chunk_bufs
+        if mem == b.MEM_HOST:
+            ctx.buffer_write(own, np.ascontiguousarray(wires, dtype=np.uint64).reshape(len(cols), n))
+        else:
+            ctx.buffer_copy(own, wires, len(cols) * n)
+        # polynomial-parallel iNTT of the own columns, then every own coefficient column to its place in column order
+        ctx.buffer_copy(cown, own, len(cols) * n)
+        if cols:
+            ctx._check(ctx.lib.lcp2_ntt_batch(ctx.handle, ctypes.c_void_p(cown), len(cols), p.degree_bits, 1, 1, b.MEM_DEVICE))
+        count = lambda r, t: sum(1 for j in range(nch) if 8 * j + r * k + t < W)  # noqa: E731  chunks in which column slot (r, t) exists
+        for t in range(k):
+            if count(rank, t):
+                ctx.buffer_copy_2d(cbase + 8 * (rank * k + t) * n, 8 * n, cown + 8 * t * n, k * n, n, count(rank, t))
+        handles = []
+        for j in range(min(2, nch)):  # two chunks in flight
+            handles.append((yield ("all_gather_async", cbase + 8 * 8 * j * n, 8 * n, k * n)))
+        # the witness values as row blocks (all-to-all), then into column order
+        for dst in range(world):
+            if cols:
+                ctx.buffer_copy_2d(send + 8 * dst * most * rows, rows, own + 8 * dst * rows, n, rows, len(cols))
+        yield ("all_to_all_device", send, recv, most * rows)
+        for src in range(world):
+            for t in range(k):
+                if count(src, t):
+                    ctx.buffer_copy_2d(rowsbuf + 8 * (src * k + t) * rows, 8 * rows, recv + 8 * (src * most + t) * rows, k * rows, rows, count(src, t))
+        d.commit_wires_rows_begin(rowsbuf)
+        for j in range(nch):
+            yield ("wait", handles[j])
+            if j + 2 < nch:
+                handles.append((yield ("all_gather_async", cbase + 8 * 8 * (j + 2) * n, 8 * n, k * n)))
+            d.commit_wires_chunk(cbase + 8 * 8 * j * n, 8 * j, min(8, W - 8 * j))
+        return d.commit_wires_rows_finish()
+
+    def prove(self, wires, public_inputs, mem=0, sharded_columns=False, row_exchange=False, chunked=False):
+        steps = self.prove_steps(wires, public_inputs, mem, sharded_columns, row_exchange, chunked)
         reply = None
         try:
             while True:
@@ -281,6 +345,13 @@ class ShardedProver:
                 elif req[0] == "all_to_all_device":
                     self.comm.all_to_all_device(req[1], req[2], req[3])
                     reply = None
+                elif req[0] == "all_gather_async":  # a communicator without the asynchronous form gathers on the spot
+                    start = getattr(self.comm, "all_gather_device_async", None)
+                    reply = start(req[1], req[2], req[3]) if start else self.comm.all_gather_device(req[1], req[2], req[3])
+                elif req[0] == "wait":
+                    if req[1] is not None:
+                        self.comm.wait(req[1])
+                    reply = None
                 else:
                     self.comm.all_gather_device(req[1], req[2], req[3])
                     reply = None
@@ -288,10 +359,10 @@ class ShardedProver:
             return self.proof
 
     def close(self):
-        for buf in [self._vals, self._coeffs] + list(self._row_bufs or []):
+        for buf in [self._vals, self._coeffs] + list(self._row_bufs or []) + list(getattr(self, "_chunk_bufs", None) or []):
             if buf:
                 self.ctx.buffer_free(buf)
-        self._vals = self._coeffs = self._row_bufs = None
+        self._vals = self._coeffs = self._row_bufs = self._chunk_bufs = None
         self.data.close()
 
 
@@ -376,6 +447,38 @@ class TorchComm:
         torch.cuda.synchronize(self.device)
         self.seconds["all_gather"] += time.perf_counter() - t0
         self.bytes_gathered += 8 * words_per_rank * (world - 1)
+
+    def all_gather_device_async(self, ptr, total_words, words_per_rank):
+        """all_gather_device on the communicator's own stream: returns an event; the library's stream (wrapped by its handle,
+        lcp2_ctx_stream) goes on with the chunk before.  What this rank contributes was written by work already queued on the library's
+        stream: the side stream waits for it.  (With TORCH_NCCL_BLOCKING_WAIT the HOST blocks inside the call until
+        the collective is done - the kernels queued before it still overlap it.)  Other backends: the synchronous form."""
+        import time
+        import torch
+        if self.dist.get_backend() != "nccl" or self.staged:
+            self.all_gather_device(ptr, total_words, words_per_rank)
+            return None
+        world = self.dist.get_world_size()
+        assert total_words == words_per_rank * world
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._lib_stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)  # the context's own stream, by handle
+        t0 = time.perf_counter()
+        ready = torch.cuda.Event()
+        ready.record(self._lib_stream)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            out = torch.as_tensor(_DevicePtr(ptr, total_words), device=self.device)
+            self.all_gather_tensor(out, self.dist.get_rank())
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self.seconds["all_gather"] += time.perf_counter() - t0  # host time inside the call (not the transfer, which runs on)
+        self.bytes_gathered += 8 * words_per_rank * (world - 1)
+        return done
+
+    def wait(self, done):
+        """the library's stream waits for an asynchronous gather; the host does not"""
+        self._lib_stream.wait_event(done)
 
     def all_to_all_tensor(self, recv, send):
         """part d of `send` goes to rank d, part s of `recv` comes from rank s (1-D tensors of world * k words)"""

@@ -97,6 +97,9 @@ int lcp2_ctx_create(int device, void *stream, lcp2_ctx **out);
 int lcp2_ctx_create_ex(int device, void *stream, uint32_t flags, lcp2_ctx **out);
 void lcp2_ctx_destroy(lcp2_ctx *ctx);
 int lcp2_ctx_sync(lcp2_ctx *ctx);
+/* the hipStream_t the context runs on (the caller's, or the private one): for callers that order their own streams against it with
+ * events - e.g. a collective on a communication stream that must wait for, and be waited for by, the library's kernels */
+void *lcp2_ctx_stream(lcp2_ctx *ctx);
 const char *lcp2_last_error(lcp2_ctx *ctx);
 
 /* ------------------------------------------------------------------ primitives
@@ -415,6 +418,18 @@ int lcp2_commit_wires_coeffs(lcp2_circuit *c, const uint64_t *wires, const uint6
  * lcp2_quotient_values then checks the gates on the rank's rows only: a caller must exchange the status (a rank that got
  * LCP2_E_UNSAT stops, and so must the others) before the next collective. */
 int lcp2_commit_wires_rows(lcp2_circuit *c, const uint64_t *wire_rows, const uint64_t *coeffs, uint64_t *cap);
+/* lcp2_commit_wires_rows with the coefficient exchange OVERLAPPED (round 4).  The sponge of a leaf absorbs the columns in order, 8 per
+ * permutation, so the commitment can proceed chunk by chunk - coset LDE of the chunk's columns, absorption into a persistent 12-word
+ * state per leaf - while later chunks are still crossing the fabric (eth-lc-plonky2_amd/parallel.py: chunks of 8 columns, one or a few per
+ * rank, gathered on a second stream):
+ *   lcp2_commit_wires_rows_begin    wire_rows as above; no coefficients yet
+ *   lcp2_commit_wires_chunk         coeffs: device, the coefficient columns [first_col, first_col + ncols) as [ncols][n].  Chunks come in
+ *                                   column order; first_col is a multiple of 8, ncols a multiple of 8 unless the chunk ends at num_wires
+ *   lcp2_commit_wires_rows_finish   after the chunk that ends at num_wires: the Merkle levels -> cap share
+ * The result is the commitment lcp2_commit_wires_rows makes (same coefficients, LDE, digests, cap). */
+int lcp2_commit_wires_rows_begin(lcp2_circuit *c, const uint64_t *wire_rows);
+int lcp2_commit_wires_chunk(lcp2_circuit *c, const uint64_t *coeffs, uint32_t first_col, uint32_t ncols);
+int lcp2_commit_wires_rows_finish(lcp2_circuit *c, uint64_t *cap);
 int lcp2_perm_zs_rows_begin(lcp2_circuit *c, const uint64_t *betas, const uint64_t *gammas, uint64_t *block_products);
 int lcp2_perm_zs_rows_finish(lcp2_circuit *c, const uint64_t *block_products, uint64_t **device_ptr, size_t *words);
 int lcp2_perm_zs_commit(lcp2_circuit *c, uint64_t *cap);

@@ -41,18 +41,8 @@ class LockstepComm:
             self.ctx.buffer_write(recv, np.ascontiguousarray(np.stack([sends[src][d] for src in range(world)])).ravel())
 
 
-def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False, row_exchange=False):
-    comm = LockstepComm(ctx)
-    ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
-    cap = comm.sum_host_all([r.cap_share for r in ranks])
-    for r in ranks:
-        r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
-        r.finish_build()
-    if sharded_columns:  # every rank brings only its column shard of the witness
-        gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True, row_exchange=row_exchange)
-                for r in ranks]
-    else:
-        gens = [r.prove_steps(wires, pis) for r in ranks]
+def _drive(comm, gens, world):
+    """steps the ranks' generators in lockstep, answering their exchange requests on the host"""
     replies = [None] * world
     while True:
         reqs = []
@@ -62,7 +52,7 @@ def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False, row_ex
             except StopIteration:
                 reqs.append(None)
         if all(q is None for q in reqs):
-            break
+            return
         assert all(q is not None and q[0] == reqs[0][0] for q in reqs), "ranks diverged"
         if reqs[0][0] == "sum_host":
             merged = comm.sum_host_all([q[1] for q in reqs])
@@ -70,9 +60,29 @@ def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False, row_ex
         elif reqs[0][0] == "all_to_all_device":
             comm.all_to_all_device_all([(q[1], q[2], q[3]) for q in reqs])
             replies = [None] * world
+        elif reqs[0][0] == "wait":  # the lockstep gathers are done on the spot
+            replies = [None] * world
         else:
             comm.all_gather_device_all([(q[1], q[2], q[3]) for q in reqs])
             replies = [None] * world
+
+
+def _run_lockstep(m, ctx, circ, wires, pis, world, sharded_columns=False, row_exchange=False, chunked=False):
+    comm = LockstepComm(ctx)
+    ranks = [m.parallel.ShardedProver(ctx, circ, r, world, None) for r in range(world)]
+    cap = comm.sum_host_all([r.cap_share for r in ranks])
+    for r in ranks:
+        r.comm = type("C", (), {"sum_host": staticmethod(lambda a, cap=cap: cap)})()
+        r.finish_build()
+    if chunked:  # every rank brings the columns the chunked exchange assigns to it
+        gens = [r.prove_steps(np.ascontiguousarray(wires[m.parallel.chunk_columns(circ.params.num_wires, r.rank, world)]), pis, sharded_columns=True,
+                              row_exchange=True, chunked=True) for r in ranks]
+    elif sharded_columns:  # every rank brings only its column shard of the witness
+        gens = [r.prove_steps(np.ascontiguousarray(wires[slice(*r.column_shard())]), pis, sharded_columns=True, row_exchange=row_exchange)
+                for r in ranks]
+    else:
+        gens = [r.prove_steps(wires, pis) for r in ranks]
+    _drive(comm, gens, world)
     return ranks
 
 
@@ -98,6 +108,63 @@ def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits, sharded_co
     for r in ranks:
         r.close()
     single.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 7, 135), (1, 6, 135), (8, 4, 135), (8, 6, 140), (4, 6, 136), (8, 5, 129)])
+def test_chunked_exchange_proof_equals_single_gpu(gpu_ctx, world, degree_bits, num_wires):
+    """the row exchange form with the coefficient exchange in chunks of 8 columns (lcp2_commit_wires_rows_begin / _chunk / _finish: coset
+    LDE of a chunk and absorption into a persistent sponge state per leaf while the next chunks are gathered): the assembled proof is the
+    single-GPU proof word for word.  135 wires: the last chunk has 7 columns (rank 7 of 8 brings 16 columns, the others 17); 140: 4 in the
+    last chunk; 136: none short; 129: a last chunk of one column"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(degree_bits, 4)
+    params.num_wires = num_wires
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1500 + world + degree_bits)
+    single = m.CircuitData.build(gpu_ctx, circ)
+    want = single.prove(wires, pis)
+    ranks = _run_lockstep(m, gpu_ctx, circ, wires, pis, world, True, True, chunked=True)
+    for r in ranks:
+        bad = np.nonzero(r.proof != want)[0]
+        assert bad.size == 0, f"rank {r.rank}/{world}: {bad.size} proof words differ, first at {bad[0]}"
+    # a second chunked proof on the same handles (the persistent states and the exchange buffers are reused), then the whole-column form
+    _drive(LockstepComm(gpu_ctx), [r.prove_steps(np.ascontiguousarray(wires[m.parallel.chunk_columns(num_wires, r.rank, world)]), pis, sharded_columns=True,
+                                                 row_exchange=True, chunked=True) for r in ranks], world)
+    assert all((r.proof == want).all() for r in ranks)
+    assert (_rerun(m, gpu_ctx, ranks, wires, pis, world) == want).all()
+    for r in ranks:
+        r.close()
+    single.close()
+
+
+@pytest.mark.gpu
+def test_chunk_entry_points_enforce_their_order(gpu_ctx):
+    """lcp2_commit_wires_chunk: chunks in column order, starting at multiples of 8, only after _begin; _finish only after the last column"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(6, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=5)
+    n = 64
+    d = m.CircuitData.build_sharded(gpu_ctx, circ, 0, 8)
+    rows = gpu_ctx.buffer_alloc(135 * n)
+    coeffs = gpu_ctx.buffer_alloc(136 * n)
+    gpu_ctx.buffer_write(rows, wires)
+    with pytest.raises(m.Lcp2Error):
+        d.commit_wires_chunk(coeffs, 0, 8)       # no _begin
+    d.commit_wires_rows_begin(rows)
+    with pytest.raises(m.Lcp2Error):
+        d.commit_wires_chunk(coeffs, 8, 8)       # out of order
+    with pytest.raises(m.Lcp2Error):
+        d.commit_wires_chunk(coeffs, 0, 7)       # a short chunk that is not the last
+    d.commit_wires_chunk(coeffs, 0, 16)
+    with pytest.raises(m.Lcp2Error):
+        d.commit_wires_rows_finish()             # columns missing
+    with pytest.raises(m.Lcp2Error):
+        d.commit_wires_chunk(coeffs, 16, 128)    # past the last wire
+    d.commit_wires_chunk(coeffs + 8 * 16 * n, 16, 119)
+    d.commit_wires_rows_finish()
+    gpu_ctx.buffer_free(rows)
+    gpu_ctx.buffer_free(coeffs)
+    d.close()
 
 
 @pytest.mark.gpu
@@ -625,6 +692,38 @@ for limit in (1 << 27, 5):  # and the all-gather, whole and in pieces
     buf = torch.zeros(24, dtype=torch.int64); buf[12 * rank:12 * rank + 12] = torch.arange(12) + 50 * (rank + 1)
     cm.all_gather_tensor(buf, rank)
     assert buf.tolist() == [50 + j for j in range(12)] + [100 + j for j in range(12)], (limit, buf.tolist())
+# ---- the chunked coefficient exchange (ShardedProver._commit_wires_chunked): 19 wires = chunks of 8, 8 and 3 columns, 4 per rank and chunk
+W2 = 19
+witness2 = (np.arange(W2 * N, dtype=np.uint64).reshape(W2, N) + np.uint64(5)) * np.uint64(0x10001)
+class FakeParams2(FakeParams):
+    num_wires = W2
+class FakeCirc2:
+    params = FakeParams2()
+class ChunkData(RowsData):
+    def commit_wires_rows_begin(self, rows_ptr):
+        rows = fc.buffer_read(rows_ptr, 24 * 4).reshape(24, 4)[:W2]
+        assert (rows == witness2[:, 4 * self.rank:4 * self.rank + 4]).all(), rows     # this rank's rows of EVERY column, in column order
+        self.seen = []
+    def commit_wires_chunk(self, coeffs_ptr, first_col, ncols):
+        got = fc.buffer_read(coeffs_ptr, ncols * N).reshape(ncols, N)
+        assert (got == witness2[first_col:first_col + ncols] * np.uint64(3) + np.uint64(1)).all(), (first_col, got)   # complete when it is absorbed
+        self.seen.append((first_col, ncols))
+    def commit_wires_rows_finish(self):
+        assert self.seen == [(0, 8), (8, 8), (16, 3)], self.seen
+        return self._share(1)
+sp2 = object.__new__(m.parallel.ShardedProver)
+sp2.b, sp2.ctx, sp2.circ, sp2.rank, sp2.world, sp2.comm = m.binding, fc, FakeCirc2(), rank, 2, RowsComm(dist)
+sp2._vals = sp2._coeffs = sp2._row_bufs = sp2._chunk_bufs = None
+sp2.data = ChunkData(rank)
+sp2.digest = np.arange(4, dtype=np.uint64)
+mine = m.parallel.chunk_columns(W2, rank, 2)
+assert mine == ([0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18], [4, 5, 6, 7, 12, 13, 14, 15])[rank]
+_sp_saved, sp = sp, sp2   # RowsComm._view looks the stand-in's own buffers up through `sp`
+proof2 = sp2.prove(witness2[mine].copy(), np.array([3, 4], dtype=np.uint64), sharded_columns=True, row_exchange=True, chunked=True)
+gathered = [None, None]
+dist.all_gather_object(gathered, proof2.tobytes())
+assert gathered[0] == gathered[1] and (proof2[:192].reshape(3, 16, 4) != 0).all()
+sp = _sp_saved
 # a gate violation found by one rank stops both, after the verdict exchange and before the next collective
 sp.data.fail_check = True
 try:
@@ -656,5 +755,6 @@ def _run_gloo_pair(tmp_path, text):
 
 def test_row_exchange_over_gloo(tmp_path):
     """world_size-2 gloo: the all-to-all of row blocks, the all-gather of the Z / partial-product rows, the block-product and
-    gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True)"""
+    gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True); then the chunked form (chunked=True): 19 wires in
+    chunks of 8, 8 and 3 columns, every chunk complete - gathered from both ranks - when it is handed to the commitment, in column order"""
     _run_gloo_pair(tmp_path, _GLOO_ROWS_WORKER)

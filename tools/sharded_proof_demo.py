@@ -33,9 +33,10 @@ class _Rehearsal(_Solo):
     filled from the whole witness - a rank checks the witness it proves, so the values must be the real ones.  The time spent in
     here is not the rank's compute."""
 
-    def __init__(self, m, ctx, d_wires, num_wires, n, world, rank=0, row_exchange=False, num_challenges=2):
+    def __init__(self, m, ctx, d_wires, num_wires, n, world, rank=0, row_exchange=False, num_challenges=2, chunked=False):
         self.m, self.ctx, self.d_wires, self.n, self.calls, self.seconds = m, ctx, d_wires, n, 0, 0.0
         self.shards = m.parallel.column_shards(num_wires, world)
+        self.chunk_cols = [m.parallel.chunk_columns(num_wires, r, world) for r in range(world)] if chunked else None
         self.world, self.rank, self.row_exchange, self.ch = world, rank, row_exchange, num_challenges
 
     def sum_host(self, a):
@@ -58,8 +59,13 @@ class _Rehearsal(_Solo):
         torch.cuda.synchronize()
         t0 = time.time()
         rows = self.n // self.world
-        for r, (s, e) in enumerate(self.shards):
-            self.ctx.buffer_copy_2d(recv_ptr + 8 * r * words_per_pair, rows, self.d_wires.data_ptr() + 8 * (s * self.n + self.rank * rows), self.n, rows, e - s)
+        if self.chunk_cols is not None:  # the chunked form: rank r's columns are chunk_columns(.., r, ..), in that order
+            for r, cols in enumerate(self.chunk_cols):
+                for i, col in enumerate(cols):
+                    self.ctx.buffer_copy(recv_ptr + 8 * (r * words_per_pair + i * rows), self.d_wires.data_ptr() + 8 * (col * self.n + self.rank * rows), rows)
+        else:
+            for r, (s, e) in enumerate(self.shards):
+                self.ctx.buffer_copy_2d(recv_ptr + 8 * r * words_per_pair, rows, self.d_wires.data_ptr() + 8 * (s * self.n + self.rank * rows), self.n, rows, e - s)
         torch.cuda.synchronize()
         self.seconds += time.time() - t0
 
@@ -82,6 +88,8 @@ def main():
     ap.add_argument("--sharded-columns", action="store_true", help="the witness arrives column-sharded (all-gather of values and coefficients)")
     ap.add_argument("--row-exchange", action="store_true", help="with --sharded-columns: the values cross the ranks as row blocks "
                     "(all-to-all), K5 and the gate check run on a rank's own rows (include/lcp2.h, the row exchange form)")
+    ap.add_argument("--chunked", action="store_true", help="with --row-exchange: the coefficient exchange in chunks of 8 columns, overlapped with "
+                    "the commitment (lcp2_commit_wires_chunk); the ranks bring the columns parallel.chunk_columns assigns to them")
     ap.add_argument("--rehearse", default="", help="R/W: time the compute of rank R of W on this one GPU (collectives replaced by "
                     "the identity, so the transcript is not the real one and the proof is not verified)")
     a = ap.parse_args()
@@ -107,9 +115,11 @@ def main():
     d_wires = torch.from_numpy(wires.view("int64")).cuda()  # witness resident in HBM, as in bench.py
     n = 1 << a.degree_bits
     if rehearse and a.sharded_columns:
-        prover.comm = comm = _Rehearsal(m, ctx, d_wires, params.num_wires, n, world, rank, a.row_exchange, params.num_challenges)
+        prover.comm = comm = _Rehearsal(m, ctx, d_wires, params.num_wires, n, world, rank, a.row_exchange, params.num_challenges, a.chunked)
     first, end = prover.column_shard()
     mine = d_wires[first:end].contiguous() if a.sharded_columns else d_wires
+    if a.chunked:
+        mine = d_wires[torch.tensor(m.parallel.chunk_columns(params.num_wires, rank, world), device=d_wires.device)].contiguous()
     times = []
     ctx.prof_enable(True)
     for _ in range(a.reps):
@@ -120,14 +130,14 @@ def main():
         ctx.prof_reset()
         torch.cuda.synchronize()
         t0 = time.time()
-        proof = prover.prove(mine.data_ptr(), pis, mem=m.MEM_DEVICE, sharded_columns=a.sharded_columns, row_exchange=a.row_exchange)
+        proof = prover.prove(mine.data_ptr(), pis, mem=m.MEM_DEVICE, sharded_columns=a.sharded_columns, row_exchange=a.row_exchange, chunked=a.chunked)
         torch.cuda.synchronize()
         times.append(time.time() - t0 - (comm.seconds if isinstance(comm, _Rehearsal) else 0.0))
     fam = ", ".join("%s %.1f" % (k, v["ms"]) for k, v in ctx.prof_get().items() if v["ms"] > 0.05)
     if rehearse:
         print("rehearsal of rank %d of %d, degree_bits %d%s: build %.2f s, per-rank compute of a sharded proof %s ms (exchanges excluded); "
               "kernel families of the last proof (ms): %s"
-              % (rank, world, a.degree_bits, (", column-sharded witness" + (", row exchange" if a.row_exchange else "")) if a.sharded_columns else "", build_s,
+              % (rank, world, a.degree_bits, (", column-sharded witness" + (", row exchange" if a.row_exchange else "") + (", chunked coefficient exchange" if a.chunked else "")) if a.sharded_columns else "", build_s,
                  ", ".join("%.1f" % (1e3 * t) for t in times), fam))
         return
     if rank == 0:
