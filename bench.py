@@ -239,6 +239,13 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     first, end = prover.column_shard()
     shard_ptr = w_dev.data_ptr() + 8 * first * n
     rows = bool(comm.row_exchange_ok) and os.environ.get("LCP2_SHARDED_WHOLE_COLUMNS", "0") != "1"
+    # the coefficient exchange in chunks of 16 columns, gathered on a side stream while the chunk before is extended and absorbed
+    chunked = rows and os.environ.get("LCP2_SHARDED_UNCHUNKED", "0") != "1"
+    if chunked:  # this rank's columns of the chunked assignment, gathered out of the resident tensor (stands in for the column-sharded upload)
+        cols = torch.tensor(m.parallel.chunk_columns(circ.params.num_wires, rank, world), device=dev)
+        mine = w_dev.view(circ.params.num_wires, n)[cols].contiguous()
+        shard_ptr = mine.data_ptr()
+        torch.cuda.synchronize()
     times = []
     for it in range(reps + 1):
         torch.cuda.synchronize()
@@ -246,7 +253,7 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
         comm.bytes_gathered = 0
         comm.seconds = dict.fromkeys(comm.seconds, 0.0)
         t0 = time.perf_counter()
-        proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True, row_exchange=rows)
+        proof = prover.prove(shard_ptr, pis, mem=m.MEM_DEVICE, sharded_columns=True, row_exchange=rows, chunked=chunked)
         torch.cuda.synchronize()
         dist.barrier()
         if it:  # the first proof warms RCCL's channels up
@@ -262,6 +269,8 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
     return {"workload": "configs[3]: a n=2^%d proof (synthetic circuit over plonky2's gate set) sharded by LDE coset over %d GPUs, witness arriving column-sharded" % (circ.params.degree_bits, world),
             "ms_per_proof": float(tt.item()) * 1e3, "world": world, "rccl_world_size": dist.get_world_size(), "proof_verified": ok,
             "all_gather_form": form, "witness_values_exchange": "all-to-all of row blocks" if rows else "all-gather of whole columns",
+            "coefficient_exchange": ("chunks of %d columns gathered on a side stream, overlapped with their coset LDE and leaf absorption" % m.parallel.CHUNK_COLS) if chunked
+                                    else "one all-gather before the commitment",
             "exchange_bytes_received_per_rank": int(comm.bytes_gathered),
             "exchange_ms_rank0_last_proof": {k: round(1e3 * v, 3) for k, v in comm.seconds.items()},  # wall time inside the synchronous collectives
             "exchange": ("RCCL all_gather_into_tensor (in place): witness coefficients, %s, %d planes of per-coset quotient interpolants; %s"

@@ -111,12 +111,12 @@ def test_sharded_proof_equals_single_gpu(gpu_ctx, world, degree_bits, sharded_co
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 7, 135), (1, 6, 135), (8, 4, 135), (8, 6, 140), (4, 6, 136), (8, 5, 129)])
+@pytest.mark.parametrize("world,degree_bits,num_wires", [(8, 10, 135), (4, 8, 135), (2, 7, 135), (1, 6, 135), (8, 4, 135), (8, 6, 140), (4, 6, 144), (8, 5, 145)])
 def test_chunked_exchange_proof_equals_single_gpu(gpu_ctx, world, degree_bits, num_wires):
     """the row exchange form with the coefficient exchange in chunks of 8 columns (lcp2_commit_wires_rows_begin / _chunk / _finish: coset
     LDE of a chunk and absorption into a persistent sponge state per leaf while the next chunks are gathered): the assembled proof is the
-    single-GPU proof word for word.  135 wires: the last chunk has 7 columns (rank 7 of 8 brings 16 columns, the others 17); 140: 4 in the
-    last chunk; 136: none short; 129: a last chunk of one column"""
+    single-GPU proof word for word.  Chunks are 16 columns (parallel.CHUNK_COLS).  135 wires: the last chunk has 7 columns (at 8 ranks: ranks 0-2
+    bring 18 columns, rank 3 17, ranks 4-7 16); 140: 12 in the last chunk; 144: none short; 145: a last chunk of one column"""
     import eth_lc_plonky2_amd as m
     params = m.standard_params(degree_bits, 4)
     params.num_wires = num_wires
@@ -692,8 +692,8 @@ for limit in (1 << 27, 5):  # and the all-gather, whole and in pieces
     buf = torch.zeros(24, dtype=torch.int64); buf[12 * rank:12 * rank + 12] = torch.arange(12) + 50 * (rank + 1)
     cm.all_gather_tensor(buf, rank)
     assert buf.tolist() == [50 + j for j in range(12)] + [100 + j for j in range(12)], (limit, buf.tolist())
-# ---- the chunked coefficient exchange (ShardedProver._commit_wires_chunked): 19 wires = chunks of 8, 8 and 3 columns, 4 per rank and chunk
-W2 = 19
+# ---- the chunked coefficient exchange (ShardedProver._commit_wires_chunked): 35 wires = chunks of 16, 16 and 3 columns, 8 per rank and chunk
+W2 = 35
 witness2 = (np.arange(W2 * N, dtype=np.uint64).reshape(W2, N) + np.uint64(5)) * np.uint64(0x10001)
 class FakeParams2(FakeParams):
     num_wires = W2
@@ -701,7 +701,7 @@ class FakeCirc2:
     params = FakeParams2()
 class ChunkData(RowsData):
     def commit_wires_rows_begin(self, rows_ptr):
-        rows = fc.buffer_read(rows_ptr, 24 * 4).reshape(24, 4)[:W2]
+        rows = fc.buffer_read(rows_ptr, 48 * 4).reshape(48, 4)[:W2]
         assert (rows == witness2[:, 4 * self.rank:4 * self.rank + 4]).all(), rows     # this rank's rows of EVERY column, in column order
         self.seen = []
     def commit_wires_chunk(self, coeffs_ptr, first_col, ncols):
@@ -709,7 +709,7 @@ class ChunkData(RowsData):
         assert (got == witness2[first_col:first_col + ncols] * np.uint64(3) + np.uint64(1)).all(), (first_col, got)   # complete when it is absorbed
         self.seen.append((first_col, ncols))
     def commit_wires_rows_finish(self):
-        assert self.seen == [(0, 8), (8, 8), (16, 3)], self.seen
+        assert self.seen == [(0, 16), (16, 16), (32, 3)], self.seen
         return self._share(1)
 sp2 = object.__new__(m.parallel.ShardedProver)
 sp2.b, sp2.ctx, sp2.circ, sp2.rank, sp2.world, sp2.comm = m.binding, fc, FakeCirc2(), rank, 2, RowsComm(dist)
@@ -717,7 +717,7 @@ sp2._vals = sp2._coeffs = sp2._row_bufs = sp2._chunk_bufs = None
 sp2.data = ChunkData(rank)
 sp2.digest = np.arange(4, dtype=np.uint64)
 mine = m.parallel.chunk_columns(W2, rank, 2)
-assert mine == ([0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18], [4, 5, 6, 7, 12, 13, 14, 15])[rank]
+assert mine == (list(range(0, 8)) + list(range(16, 24)) + [32, 33, 34], list(range(8, 16)) + list(range(24, 32)))[rank]
 _sp_saved, sp = sp, sp2   # RowsComm._view looks the stand-in's own buffers up through `sp`
 proof2 = sp2.prove(witness2[mine].copy(), np.array([3, 4], dtype=np.uint64), sharded_columns=True, row_exchange=True, chunked=True)
 gathered = [None, None]
@@ -755,6 +755,6 @@ def _run_gloo_pair(tmp_path, text):
 
 def test_row_exchange_over_gloo(tmp_path):
     """world_size-2 gloo: the all-to-all of row blocks, the all-gather of the Z / partial-product rows, the block-product and
-    gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True); then the chunked form (chunked=True): 19 wires in
-    chunks of 8, 8 and 3 columns, every chunk complete - gathered from both ranks - when it is handed to the commitment, in column order"""
+    gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True); then the chunked form (chunked=True): 35 wires in
+    chunks of 16, 16 and 3 columns, every chunk complete - gathered from both ranks - when it is handed to the commitment, in column order"""
     _run_gloo_pair(tmp_path, _GLOO_ROWS_WORKER)
