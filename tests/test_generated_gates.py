@@ -87,8 +87,8 @@ def _interpret(code, imm, wires, consts, pis, forward, alpha):
     reg = [0] * 256
     emitted = []
 
-    def operand(kind, idx):
-        return (reg[idx], wires[idx], consts[idx] if kind == 2 else 0, imm[idx] if kind == 3 else 0, pis[idx] if kind == 4 else 0)[kind] if kind != 1 else wires[idx]
+    def operand(kind, idx):  # 0 REG, 1 WIRE, 2 CONST (gate constant, after the selector columns), 3 IMM, 4 PI
+        return (reg, wires, consts, imm, pis)[kind][idx]
 
     MDS_CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
     for pc in range(len(code) // 2):
