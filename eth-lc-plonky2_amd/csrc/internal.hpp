@@ -33,8 +33,12 @@ struct lcp2_ctx {
   // pinned host staging for the small device-to-host copies of a proof (caps, openings, flags, query answers): a copy into pinned
   // memory is a plain DMA that the stream orders; into pageable memory the runtime stages it and blocks
   void *pin = nullptr;
-  static constexpr size_t PIN_BYTES = 1u << 20;
+  static constexpr size_t PIN_BYTES = 4u << 20;
   hipStream_t copy_stream = nullptr;  // uploads of staged host witnesses (lcp2_witness_stage), created at the first use
+  // device scratch of the witness-generation entry points (job lists, message words, round records, cell lists): kept and grown,
+  // not allocated and freed per call (a hipMalloc / hipFree pair costs more than the kernels of a light-client step's witness)
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[4] = {0, 0, 0, 0};
 
   int fail(int code, const std::string &msg) {
     last_error = msg;

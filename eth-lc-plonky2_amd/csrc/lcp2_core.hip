@@ -87,6 +87,7 @@ extern "C" void lcp2_ctx_destroy(lcp2_ctx *ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->d_rc) (void)hipFree(ctx->d_rc);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  for (void *q : ctx->scratch) if (q) (void)hipFree(q);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -504,6 +505,30 @@ extern "C" int lcp2_oracle_read(lcp2_oracle *o, uint64_t *coeffs, uint64_t *lde)
   return LCP2_OK;
 }
 
+// scratch slot `slot` of the context with at least `bytes` bytes (contents undefined); the stream orders its reuse
+static int scratch_ensure(lcp2_ctx *ctx, int slot, size_t bytes, void **out) {
+  if (ctx->scratch_bytes[slot] < bytes) {
+    if (ctx->scratch[slot]) { LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream)); LCP2_HIP(ctx, hipFree(ctx->scratch[slot])); ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    LCP2_HIP(ctx, hipMalloc(&ctx->scratch[slot], want));
+    ctx->scratch_bytes[slot] = want;
+  }
+  *out = ctx->scratch[slot];
+  return LCP2_OK;
+}
+// host -> device through the pinned staging buffer when the piece fits (a plain DMA the stream orders; the caller's memory is free
+// again on return), else straight from the caller's memory
+static int upload_small(lcp2_ctx *ctx, void *dst, const void *src, size_t bytes, size_t *pin_used) {
+  if (ctx->pin && *pin_used + bytes <= lcp2_ctx::PIN_BYTES) {
+    memcpy((char *)ctx->pin + *pin_used, src, bytes);
+    LCP2_HIP(ctx, hipMemcpyAsync(dst, (char *)ctx->pin + *pin_used, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *pin_used += (bytes + 63) & ~(size_t)63;
+    return LCP2_OK;
+  }
+  LCP2_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return LCP2_OK;
+}
+
 // ------------------------------------------------------------------ K10: witness generation, device buffers
 static_assert(sizeof(lcp2_sha_job) == sizeof(ShaJobDev) && sizeof(lcp2_cell) == sizeof(CellDev), "ABI structs must match the kernels'");
 
@@ -524,27 +549,30 @@ extern "C" int lcp2_sha256_witness(lcp2_ctx *ctx, const lcp2_sha_job *jobs, size
     }
   }
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf d_jobs, d_words, d_rec;
-  LCP2_HIP(ctx, d_jobs.alloc(njobs * sizeof(lcp2_sha_job)));
-  LCP2_HIP(ctx, d_words.alloc(std::max<size_t>(nwords, 1) * 4));
-  LCP2_HIP(ctx, d_rec.alloc(njobs * (size_t)SHA_REC_WORDS * 4));
-  LCP2_HIP(ctx, hipMemcpyAsync(d_jobs.p, jobs, njobs * sizeof(lcp2_sha_job), hipMemcpyHostToDevice, ctx->stream));
-  if (nwords) LCP2_HIP(ctx, hipMemcpyAsync(d_words.p, words_in, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+  // (the pinned staging buffer is free here: every earlier transfer through it has been waited for)
+  void *d_jobs, *d_words, *d_rec;
+  LCP2_TRY(scratch_ensure(ctx, 0, njobs * sizeof(lcp2_sha_job), &d_jobs));
+  LCP2_TRY(scratch_ensure(ctx, 1, std::max<size_t>(nwords, 1) * 4, &d_words));
+  LCP2_TRY(scratch_ensure(ctx, 2, njobs * (size_t)SHA_REC_WORDS * 4, &d_rec));
+  size_t pin_used = 0;
+  LCP2_TRY(upload_small(ctx, d_jobs, jobs, njobs * sizeof(lcp2_sha_job), &pin_used));
+  if (nwords) LCP2_TRY(upload_small(ctx, d_words, words_in, nwords * 4, &pin_used));
   {
     ProfScope ps(ctx, LCP2_K_SHA256, 96.0 * njobs + 8.0 * 108 * SHA_ROWS * njobs);
     for (uint32_t l = 0; l < nlevels; l++)
-      launch_sha_jobs_level(ctx->stream, (const ShaJobDev *)d_jobs.p, level_start[l], level_start[l + 1] - level_start[l],
-                            (const uint32_t *)d_words.p, (uint32_t *)d_rec.p);
-    launch_sha_fill_rows(ctx->stream, (const ShaJobDev *)d_jobs.p, (u32)njobs, (const uint32_t *)d_rec.p, (u64 *)wires, n);
+      launch_sha_jobs_level(ctx->stream, (const ShaJobDev *)d_jobs, level_start[l], level_start[l + 1] - level_start[l],
+                            (const uint32_t *)d_words, (uint32_t *)d_rec);
+    launch_sha_fill_rows(ctx->stream, (const ShaJobDev *)d_jobs, (u32)njobs, (const uint32_t *)d_rec, (u64 *)wires, n);
   }
   LCP2_HIP(ctx, hipGetLastError());
-  if (digests) {
-    std::vector<uint32_t> rec(njobs * (size_t)SHA_REC_WORDS);
-    LCP2_HIP(ctx, hipMemcpyAsync(rec.data(), d_rec.p, rec.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t j = 0; j < njobs; j++) memcpy(digests + 8 * j, rec.data() + j * SHA_REC_WORDS + SHA_REC_DIGEST, 32);
-  }
-  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the temporaries are freed on return
+  // the 8 digest words of every job's record, as one strided copy (not the whole record buffer), through the pinned staging buffer
+  // when they fit behind the uploads
+  const bool via_pin = digests && ctx->pin && pin_used + njobs * 32 <= lcp2_ctx::PIN_BYTES;
+  if (digests)
+    LCP2_HIP(ctx, hipMemcpy2DAsync(via_pin ? (void *)((char *)ctx->pin + pin_used) : (void *)digests, 32, (const uint32_t *)d_rec + SHA_REC_DIGEST,
+                                   (size_t)SHA_REC_WORDS * 4, 32, njobs, hipMemcpyDeviceToHost, ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's job list and words may go; the digests have landed
+  if (via_pin) memcpy(digests, (const char *)ctx->pin + pin_used, njobs * 32);
   return LCP2_OK;
 }
 
@@ -554,12 +582,13 @@ extern "C" int lcp2_scatter_cells(lcp2_ctx *ctx, const lcp2_cell *cells, size_t 
   for (size_t i = 0; i < ncells; i++)
     if (cells[i].row >= n) return ctx->fail(LCP2_E_INVALID, "scatter: row out of range");
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf d;
-  LCP2_HIP(ctx, d.alloc(ncells * sizeof(lcp2_cell)));
-  LCP2_HIP(ctx, hipMemcpyAsync(d.p, cells, ncells * sizeof(lcp2_cell), hipMemcpyHostToDevice, ctx->stream));
-  launch_scatter_cells(ctx->stream, (const CellDev *)d.p, ncells, (u64 *)wires, n);
+  void *d;
+  LCP2_TRY(scratch_ensure(ctx, 3, ncells * sizeof(lcp2_cell), &d));
+  size_t pin_used = 0;
+  LCP2_TRY(upload_small(ctx, d, cells, ncells * sizeof(lcp2_cell), &pin_used));  // (a list pinned by the caller - lcp2_host_register - goes up as a DMA too)
+  launch_scatter_cells(ctx->stream, (const CellDev *)d, ncells, (u64 *)wires, n);
   LCP2_HIP(ctx, hipGetLastError());
-  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's list may go
   return LCP2_OK;
 }
 
@@ -570,10 +599,11 @@ extern "C" int lcp2_poseidon_gate_rows(lcp2_ctx *ctx, const lcp2_poseidon_row *r
   for (size_t i = 0; i < nrows; i++)
     if (rows[i].row >= n || rows[i].swap > 1) return ctx->fail(LCP2_E_INVALID, "poseidon rows: row out of range or swap flag not boolean");
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
-  DevBuf d;
-  LCP2_HIP(ctx, d.alloc(nrows * sizeof(lcp2_poseidon_row)));
-  LCP2_HIP(ctx, hipMemcpyAsync(d.p, rows, nrows * sizeof(lcp2_poseidon_row), hipMemcpyHostToDevice, ctx->stream));
-  launch_poseidon_gate_rows(ctx->stream, (const PoseidonRowDev *)d.p, nrows, (u64 *)wires, n, ctx->d_rc);
+  void *d;
+  LCP2_TRY(scratch_ensure(ctx, 0, nrows * sizeof(lcp2_poseidon_row), &d));
+  size_t pin_used = 0;
+  LCP2_TRY(upload_small(ctx, d, rows, nrows * sizeof(lcp2_poseidon_row), &pin_used));
+  launch_poseidon_gate_rows(ctx->stream, (const PoseidonRowDev *)d, nrows, (u64 *)wires, n, ctx->d_rc);
   LCP2_HIP(ctx, hipGetLastError());
   LCP2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the job list is freed on return
   return LCP2_OK;

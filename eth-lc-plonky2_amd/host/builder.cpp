@@ -367,23 +367,31 @@ lcp2_circuit_desc CircuitDescription::c_desc() const {
 namespace {
 struct Values {
   const CircuitData::Impl *d;
-  std::vector<F> val;
-  std::vector<uint8_t> has;
-  explicit Values(const CircuitData::Impl *dd) : d(dd), val(dd->parent.size(), 0), has(dd->parent.size(), 0) {}
-  // The generators of one phase may run on several threads (run_host_phase, LCP2_HOST_LANES > 1).  A slot goes 0 (empty) -> 2 (claimed:
-  // one writer is storing the value) -> 1 (published); the claim is a compare-and-swap, so exactly one generator writes val[r] and
-  // every other one - on any lane - compares with the published value: two generators that disagree about a connected class are
-  // always reported, never a torn or lost write.
-  bool known(uint32_t r) const { return __atomic_load_n(&has[r], __ATOMIC_ACQUIRE) == 1; }
+  F *val;
+  uint32_t *stamp;
+  uint32_t epoch;
+  static constexpr uint32_t CLAIM = 0x80000000u;
+  explicit Values(const CircuitData::Impl *dd) : d(dd) {
+    if (dd->value_store.size() != dd->parent.size()) { dd->value_store.assign(dd->parent.size(), 0); dd->stamp_store.assign(dd->parent.size(), 0); dd->epoch = 0; }
+    if (++dd->epoch >= CLAIM) { std::fill(dd->stamp_store.begin(), dd->stamp_store.end(), 0u); dd->epoch = 1; }  // once in 2^31 proofs
+    val = dd->value_store.data(); stamp = dd->stamp_store.data(); epoch = dd->epoch;
+  }
+  // The generators of one phase may run on several threads (run_host_phase, LCP2_HOST_LANES > 1).  A slot is empty while its stamp
+  // is not this proof's epoch, claimed (one writer is storing the value) with epoch | CLAIM, published with epoch; the claim is a
+  // compare-and-swap, so exactly one generator writes val[r] and every other one - on any lane - compares with the published value:
+  // two generators that disagree about a connected class are always reported, never a torn or lost write.
+  bool known(uint32_t r) const { return __atomic_load_n(&stamp[r], __ATOMIC_ACQUIRE) == epoch; }
   void set(uint32_t var, F v, const char *what) {
     uint32_t r = d->find(var);
-    uint8_t expected = 0;
-    if (__atomic_compare_exchange_n(&has[r], &expected, (uint8_t)2, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
-      val[r] = v;
-      __atomic_store_n(&has[r], (uint8_t)1, __ATOMIC_RELEASE);
-      return;
+    uint32_t seen = __atomic_load_n(&stamp[r], __ATOMIC_ACQUIRE);
+    while ((seen & ~CLAIM) != epoch) {  // empty (a stamp of an earlier proof): try to claim it
+      if (__atomic_compare_exchange_n(&stamp[r], &seen, epoch | CLAIM, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+        val[r] = v;
+        __atomic_store_n(&stamp[r], epoch, __ATOMIC_RELEASE);
+        return;
+      }
     }
-    while (__atomic_load_n(&has[r], __ATOMIC_ACQUIRE) != 1) {}  // another lane is between its claim and its store: a few cycles
+    while (__atomic_load_n(&stamp[r], __ATOMIC_ACQUIRE) != epoch) {}  // another lane is between its claim and its store: a few cycles
     if (val[r] != v)
       throw UnsatisfiedError(std::string("witness conflict on a connected target (") + what + "): " + std::to_string(val[r]) + " vs " + std::to_string(v));
   }
@@ -586,6 +594,7 @@ void CircuitData::generate_witness(const PartialWitness &pw, std::vector<uint64_
 // ------------------------------------------------------------------ prove / verify through the C ABI
 CircuitData::~CircuitData() {
   if (impl_) {
+    if (impl_->cell_buf_pinned) lcp2_host_unregister(impl_->ctx, impl_->cell_buf.data());
     if (impl_->d_wires) lcp2_buffer_free(impl_->ctx, impl_->d_wires);
     if (impl_->gpu) lcp2_circuit_destroy(impl_->gpu);
     if (impl_->verifier) lcp2_circuit_destroy(impl_->verifier);
@@ -805,7 +814,7 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
       size_t words_mark = words.size();
       for (int i = 0; i < 16 && ok; i++) {
         uint32_t r = d->find(op->in[i]);
-        if (V.has[r]) { job.in_src[i] = (int32_t)words.size(); words.push_back(as_u32(V.val[r], "sha256 message word")); word_vars.push_back(r); }
+        if (V.known(r)) { job.in_src[i] = (int32_t)words.size(); words.push_back(as_u32(V.val[r], "sha256 message word")); word_vars.push_back(r); }
         else {
           auto it = produced.find(r);
           if (it == produced.end()) ok = false;
@@ -869,18 +878,27 @@ void CircuitData::generate_witness_gpu(const PartialWitness &pw, std::vector<F> 
     if (recording) { fresh.batches = std::move(recorded.batches); fresh.ready = true; }
     d->gpu_plan = std::move(fresh);  // not ready if this proof left the recorded plan half way: the next one records again
   }
-  cells.reserve(cells.size() + d->gpu_plan.host_cells.size());
-  for (const CellBinding &c : d->gpu_plan.host_cells) {
-    if (!V.known(c.var)) throw UnsatisfiedError("target has no value: wire cell");
-    cells.push_back(lcp2_cell{c.row, c.col, V.val[c.var]});
+  // the planned cells: rows and columns were filled when the plan was made, only the values change from proof to proof
+  std::vector<lcp2_cell> &buf = d->cell_buf;
+  if (buf.size() != d->gpu_plan.host_cells.size()) {
+    if (d->cell_buf_pinned) { lcp2_host_unregister(d->ctx, buf.data()); d->cell_buf_pinned = false; }
+    buf.resize(d->gpu_plan.host_cells.size());
+    for (size_t k = 0; k < buf.size(); k++) { buf[k].row = d->gpu_plan.host_cells[k].row; buf[k].col = d->gpu_plan.host_cells[k].col; }
+    if (!buf.empty()) d->cell_buf_pinned = lcp2_host_register(d->ctx, buf.data(), buf.size() * sizeof(lcp2_cell)) == LCP2_OK;  // (unpinned it still works)
+  }
+  for (size_t k = 0; k < buf.size(); k++) {
+    const uint32_t var = d->gpu_plan.host_cells[k].var;
+    if (!V.known(var)) throw UnsatisfiedError("target has no value: wire cell");
+    buf[k].value = V.val[var];
   }
   const auto t_scatter = now();
-  rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);
+  rc = lcp2_scatter_cells(d->ctx, buf.data(), buf.size(), (uint64_t *)d->d_wires, n);
+  if (rc == LCP2_OK) rc = lcp2_scatter_cells(d->ctx, cells.data(), cells.size(), (uint64_t *)d->d_wires, n);  // what the generators of this proof wrote cell by cell
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_scatter_cells: ") + lcp2_status_str(rc));
   if (prof)
     printf("  witness generation %.2f ms: host generators %.2f ms on %u lane(s) (%zu sweeps, %zu visits of %zu ops, %zu PoseidonGate rows), SHA-256 batches %.2f ms, "
            "PoseidonGate rows on the device + cell list %.2f ms, scatter of %zu cells %.2f ms\n",
-           ms(t_begin, now()), t_host, d->host_lanes.lanes, st.sweeps, st.visits, d->ops.size(), pos_rows.size(), ms(t_begin, t_rows) - t_host, ms(t_rows, t_scatter), cells.size(), ms(t_scatter, now()));
+           ms(t_begin, now()), t_host, d->host_lanes.lanes, st.sweeps, st.visits, d->ops.size(), pos_rows.size(), ms(t_begin, t_rows) - t_host, ms(t_rows, t_scatter), cells.size() + buf.size(), ms(t_scatter, now()));
   public_inputs.clear();
   for (uint32_t v : d->public_inputs) public_inputs.push_back(V.get(v, "public input"));
 }
@@ -914,4 +932,22 @@ void CircuitData::verify(const ProofWithPublicInputs &proof) const {
   if (rc != LCP2_OK) throw std::runtime_error(std::string("lcp2_verify: ") + lcp2_status_str(rc));
 }
 
+}  // namespace lc
+
+// diagnostics for tools (how a circuit's witness generation is made up)
+namespace lc {
+struct OpStats { size_t kinds[16]; size_t ops, vars, cells, const_cells; };
+OpStats op_stats(const CircuitData &data) {
+  const CircuitData::Impl *d = data.impl_for_tools();
+  OpStats s{};
+  s.ops = d->ops.size(); s.vars = d->parent.size(); s.cells = d->cells.size();
+  std::vector<uint8_t> is_const(d->parent.size(), 0);
+  for (const Op &op : d->ops) { s.kinds[op.kind]++; if (op.kind == Op::CONST) is_const[d->find(op.out)] = 1; }
+  for (const CellBinding &c : d->cells) {
+    const uint32_t g = d->gate_of_row[c.row];
+    if (g == G_SHA_ADD || g == G_SHA_ROUND_A || g == G_SHA_ROUND_E || g == G_SHA_SCHED || g == G_POSEIDON) { s.cells--; continue; }
+    s.const_cells += is_const[d->find(c.var)];
+  }
+  return s;
+}
 }  // namespace lc

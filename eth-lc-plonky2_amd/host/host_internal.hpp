@@ -106,6 +106,16 @@ struct CircuitData::Impl {
   lcp2_circuit *verifier = nullptr;
   HostLanes host_lanes;                   // planned at the first prove
   GpuWitnessPlan gpu_plan;
+  // the value table of a witness generation (builder.cpp Values), kept between proofs: a slot is valid when its stamp carries the
+  // current epoch, so a new proof costs one increment instead of clearing 9 bytes per variable (3.6 M variables in the 2^22-row
+  // circuit: ~3 ms).  One witness generation at a time per CircuitData (prove() is not const).
+  // the host-written cells of a proof as the list lcp2_scatter_cells takes: rows and columns filled once (GpuWitnessPlan::host_cells),
+  // the values refreshed per proof; pinned (lcp2_host_register) so that its upload is a DMA
+  std::vector<lcp2_cell> cell_buf;
+  bool cell_buf_pinned = false;
+  mutable std::vector<F> value_store;
+  mutable std::vector<uint32_t> stamp_store;
+  mutable uint32_t epoch = 0;
   uint32_t find(uint32_t v) const { while (parent[v] != v) v = parent[v]; return v; }
 };
 

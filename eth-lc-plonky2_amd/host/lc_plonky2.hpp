@@ -169,6 +169,7 @@ class CircuitData {
   void read_device_witness(std::vector<uint64_t> &wires) const;   // test helper: copy of the device witness matrix
   void verify(const ProofWithPublicInputs &proof) const;          // data.verify(proof): host only
   struct Impl;
+  const Impl *impl_for_tools() const { return impl_.get(); }  // diagnostics (op_stats)
 
  private:
   friend class CircuitBuilder;
