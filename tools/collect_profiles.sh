@@ -23,6 +23,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/mixfetch -
 python3 tools/reference_mix_probe.py 22 3 > $out/mix_native.json 2> $out/mix_native.err && \
 python3 tools/reference_mix_probe.py 22 2 --interpreted > $out/mix_interpreted.json 2> $out/mix_interpreted.err && \
 for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal.log || exit 1; done && \
+for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --chunked --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal_chunked.log || exit 1; done && \
 python3 bench.py --force-sharded --no-cpu-baseline --no-real-gadgets --no-synthetic > $out/bench_force_sharded.json 2> $out/bench_force_sharded.err && \
 python3 tools/cpu_baseline_scaling.py 20 > $out/cpu_baseline_scaling.json 2> $out/cpu_baseline_scaling.err && \
 python3 bench.py > $out/bench.json 2> $out/bench.err

@@ -30,6 +30,8 @@ if os.path.exists(f"{src}/ubench.txt"):
     shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
 if os.path.exists(f"{src}/sharded_rehearsal.log"):
     shutil.copy(f"{src}/sharded_rehearsal.log", f"{p}/{tag}_sharded_rehearsal.log")
+if os.path.exists(f"{src}/sharded_rehearsal_chunked.log"):
+    shutil.copy(f"{src}/sharded_rehearsal_chunked.log", f"{p}/{tag}_sharded_rehearsal_chunked.log")
 if os.path.exists(f"{src}/bench_force_sharded.json"):
     json_line(f"{src}/bench_force_sharded.json", f"{p}/{tag}_bench_force_sharded.json")
 for which in ("fetch", "write"):
