@@ -106,6 +106,7 @@ def load_library():
         "lcp2_ctx_stream": (c.c_void_p, [c.c_void_p]),
         "lcp2_last_error": (c.c_char_p, [c.c_void_p]),
         "lcp2_poseidon_permute_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]),
+        "lcp2_field_mul_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int]),
         "lcp2_merkle_cap": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_uint32, c.c_int, c.c_void_p]),
         "lcp2_ntt_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int, c.c_uint64, c.c_int]),
         "lcp2_lde_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_int]),
@@ -282,6 +283,18 @@ class Context:
         s = _np_u64(states).reshape(-1, 12)
         out = np.empty_like(s)
         self._check(self.lib.lcp2_poseidon_permute_batch(self.handle, _ptr(s), _ptr(out), s.shape[0], MEM_HOST))
+        return out
+
+    def field_mul_batch(self, a, b=None):
+        """a * b elementwise with the device multiply (b None: a^7, the Poseidon S-box); operands any u64, results canonical"""
+        a = _np_u64(a).reshape(-1)
+        out = np.empty_like(a)
+        if b is None:
+            self._check(self.lib.lcp2_field_mul_batch(self.handle, _ptr(a), None, _ptr(out), a.shape[0], 1, MEM_HOST))
+        else:
+            b = _np_u64(b).reshape(-1)
+            assert a.shape == b.shape
+            self._check(self.lib.lcp2_field_mul_batch(self.handle, _ptr(a), _ptr(b), _ptr(out), a.shape[0], 0, MEM_HOST))
         return out
 
     def merkle_cap(self, leaves, cap_height):

@@ -77,89 +77,54 @@ LCP2_HD u64 gl_reduce128_nc(u64 lo, u64 hi) {
   return r;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-// gfx950: (r1:r0) = (a1:a0) * (b1:b0) mod p, lazy result.  Measured (tools/ubench): VOP3 integer ops ~4.4 cycles per
-// wave-instruction, VOP2 carry ops through vcc ~2.7, v_mad_u64_u32 is a VOP3 op like any other.  Four v_mad_u64_u32
-// build the 128-bit product, the reduction runs on vcc carry chains: 17 instructions against hipcc's 27 for the
-// portable form.  hipcc pads nothing inside an asm string, so the wait states it emits itself for the same pairs
-// (a VALU write of vcc / an SGPR -> any VALU read of it, carry-in of v_addc / v_subb and v_cndmask in either encoding alike:
-// 2 wait states) are written out as s_nop 1.  tools/check_hazards.py disassembles the built library and fails the build
-// if any such pair, hand-written or compiler-generated, has fewer.
+// gfx950: (r1:r0) = (a1:a0) * (b1:b0) mod p, lazy result, any 32-bit halves in.  Measured (tools/ubench/int_rates, mulchain): every
+// integer VALU op that is VOP3-encoded or touches vcc (v_mad_u64_u32, v_add_co / v_addc_co / v_sub_co, v_cndmask in either
+// encoding) costs ~4.3 cycles per wave-instruction; only plain 32-bit VOP1/VOP2 ops (v_mov, v_add_u32) run at ~2.5.  So the
+// multiply is written with as FEW instructions of the first kind as the arithmetic allows, which means multiply-adds wherever a
+// carry chain would otherwise run:
+//   product    p = a0 b0 ;  t = a0 b1 + p_hi ;  u = a1 b0 + t (carry c) ;  v = a1 b1 + (u_hi + c 2^32)      -> (v : u_lo : p_lo)
+//              the partial products ride in the 64-bit addend of v_mad_u64_u32: 4 multiply-adds, one select for c, and the
+//              register moves that make (p_hi, 0) and (u_hi, c) even-aligned pairs - no add-with-carry at all;
+//   reduction  x = lo + hi0 (2^32 - 1) - hi1:   t = lo - hi1, on borrow t -= 2^32 - 1, then r = hi0 (2^32 - 1) + t, on carry
+//              r += 2^32 - 1.  Both corrections are multiply-adds of a selected factor:
+//                t + sel * 0x11111111 with sel = borrow ? -15 : 0   (v_mad_i64_i32: -15 * 0x11111111 = -(2^32 - 1), the 64-bit
+//                                                                   sum wraps like the subtraction does)
+//                r + c2 * (2^32 - 1)  with c2  = carry  ? 1 : 0     (v_mad_u64_u32; r < 2^64 - 2^33 + 1 after a wrap, no second carry)
+// 12 such instructions and 2 moves (56.5 cycles per wave-multiply against 76.6 for the carry-chain form of rounds 2-4, which had 17;
+// hipcc's own lowering of the portable form has 27).  All selects use inline constants, so no constant VGPRs are held.
+// hipcc pads nothing inside an asm string, so the wait states it emits itself for the same pairs (a VALU write of vcc -> any VALU
+// read of it, carry-in of v_addc / v_subb and v_cndmask in either encoding alike: 2 wait states) are written out as s_nop 1.
+// tools/check_hazards.py disassembles the built library and fails the build if any such pair, hand-written or
+// compiler-generated, has fewer.
 __device__ __forceinline__ void gl_mul_halves(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1) {
-  u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
+  const u64 p = (u64)a0 * b0;
+  const u64 t = (u64)a0 * b1 + (p >> 32);  // < 2^64: (2^32 - 1)^2 + 2^32 - 1
+  u64 u;
   u32 c;
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\t"
       "s_nop 1\n\t"
       "v_cndmask_b32_e64 %1, 0, 1, vcc"
-      : "+v"(m), "=v"(c) : "v"(a1), "v"(b0) : "vcc");
-  const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
-  u32 lo1, hi0, hi1;  // 128-bit product = (hi1:hi0:lo1:p0)
-  asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %2, vcc, %7, %8, vcc"
-      : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
-  u32 t0, t1, e;  // t = lo - hi1 ; on borrow t -= 2^32 - 1
+      : "=&v"(u), "=&v"(c) : "v"(a1), "v"(b0), "v"(t) : "vcc");
+  const u64 v = (u64)a1 * b1 + (((u64)c << 32) | (u32)(u >> 32));  // < 2^64: the 128-bit product is (v : u_lo : p_lo)
+  const u32 p0 = (u32)p, lo1 = (u32)u, hi0 = (u32)v, hi1 = (u32)(v >> 32);
+  u32 t0, t1, sel;  // t = lo - hi1 ; sel = -15 on borrow
   asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
       "s_nop 1\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
       "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_cndmask_b32_e64 %2, 0, -15, vcc"
+      : "=&v"(t0), "=&v"(t1), "=&v"(sel) : "v"(p0), "v"(hi1), "v"(lo1) : "vcc");
+  u64 r = ((u64)t1 << 32) | t0;
+  u32 c2;  // r = t - (borrow ? 2^32 - 1 : 0) + hi0 (2^32 - 1), c2 = its carry
+  asm("v_mad_i64_i32 %0, vcc, %2, %3, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, -1, %0\n\t"
       "s_nop 1\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1) : "vcc");
-  u64 t = ((u64)t1 << 32) | t0, r;  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
-  u32 e2;
-  asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e64 %1, 0, -1, vcc"
-      : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t) : "vcc");
-  u32 q0 = (u32)r, q1 = (u32)(r >> 32);
-  asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %3, vcc"
-      : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
-}
-// The same multiply with the select constants (1 and 2^32 - 1) held in VGPRs by the caller: v_cndmask_b32 is then a VOP2
-// instruction (~2.7 cycles per wave-instruction instead of ~4.4 for the VOP3 form with inline constants, tools/ubench).
-// Used where the two registers stay live across many multiplies (the Poseidon permutation).
-__device__ __forceinline__ void gl_mul_halves_k(u32 a0, u32 a1, u32 b0, u32 b1, u32 &r0, u32 &r1, u32 k1, u32 km1) {
-  u64 p = (u64)a0 * b0, m = (u64)a0 * b1, h = (u64)a1 * b1;
-  u32 c;
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e32 %1, 0, %4, vcc"
-      : "+v"(m), "=v"(c) : "v"(a1), "v"(b0), "v"(k1) : "vcc");
-  const u32 p0 = (u32)p, p1 = (u32)(p >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
-  u32 lo1, hi0, hi1;  // 128-bit product = (hi1:hi0:lo1:p0)
-  asm("v_add_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %1, vcc, %5, %6, vcc\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %2, vcc, %7, %8, vcc"
-      : "=&v"(lo1), "=&v"(hi0), "=&v"(hi1) : "v"(p1), "v"(m0), "v"(h0), "v"(m1), "v"(h1), "v"(c) : "vcc");
-  u32 t0, t1, e;  // t = lo - hi1 ; on borrow t -= 2^32 - 1
-  asm("v_sub_co_u32 %0, vcc, %3, %4\n\t"
-      "s_nop 1\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "s_nop 1\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(t0), "=&v"(t1), "=&v"(e) : "v"(p0), "v"(hi1), "v"(lo1), "v"(km1) : "vcc");
-  u64 t = ((u64)t1 << 32) | t0, r;  // r = hi0 * (2^32 - 1) + t ; on carry r += 2^32 - 1
-  u32 e2;
-  asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
-      "s_nop 1\n\t"
-      "v_cndmask_b32_e32 %1, 0, %4, vcc"
-      : "=&v"(r), "=v"(e2) : "v"(hi0), "v"(t), "v"(km1) : "vcc");
-  u32 q0 = (u32)r, q1 = (u32)(r >> 32);
-  asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %3, vcc"
-      : "=&v"(r0), "=&v"(r1) : "v"(q0), "v"(q1), "v"(e2) : "vcc");
+      "v_cndmask_b32_e64 %1, 0, 1, vcc"
+      : "+v"(r), "=&v"(c2) : "v"(sel), "s"(0x11111111u), "v"(hi0) : "vcc");
+  u64 q;
+  asm("v_mad_u64_u32 %0, vcc, %1, -1, %2" : "=v"(q) : "v"(c2), "v"(r) : "vcc");
+  r0 = (u32)q;
+  r1 = (u32)(q >> 32);
 }
 #endif
 

@@ -32,7 +32,27 @@ __global__ __launch_bounds__(HASH_THREADS) void k_poseidon_permute_batch(const u
   for (int j = 0; j < 12; j++) out[i * 12 + j] = s[j];
 }
 
-__global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves(const u64 *__restrict__ data, u64 leaf_stride, u64 col_stride,
+// out = a * b (op 0) or a^7 (op 1: the Poseidon S-box as the hash kernels compute it), canonical; any u64 in.  The device multiply
+// of every kernel of the library (gl_mul_halves), exposed so that the tests can drive it with operands that reach the rare
+// branches of its reduction (a borrow in lo - hi_hi has probability 2^-32 on random operands).
+__global__ __launch_bounds__(HASH_THREADS) void k_field_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out,
+                                                             size_t count, u32 op) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u64 x = a[i];
+  u32 r0 = (u32)x, r1 = (u32)(x >> 32);
+  if (op == 0) {
+    const u64 y = b[i];
+    gl_mul_halves((u32)x, (u32)(x >> 32), (u32)y, (u32)(y >> 32), r0, r1);
+  } else {
+    pos_sbox_h(r0, r1);
+  }
+  out[i] = gl_canon(((u64)r1 << 32) | r0);
+#endif
+}
+
+__global__ __launch_bounds__(HASH_THREADS, 5) void k_hash_leaves(const u64 *__restrict__ data, u64 leaf_stride, u64 col_stride,
                                                                u32 leaf_len, u64 nleaves, u64 *__restrict__ digests,
                                                                const u64 *__restrict__ rc) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +84,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves(const u64 *__restr
 // The same sponge over a CHUNK of the columns of a leaf, its state kept between launches (state[j][leaf], column-major): a sharded proof
 // absorbs the coefficient chunks that have arrived while the next ones are still crossing the fabric (lcp2_commit_wires_chunk).  The
 // chunks come in column order, each but the last a multiple of 8 columns, so the permutations fall where k_hash_leaves puts them.
-__global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves_absorb(const u64 *__restrict__ data, u64 col_stride, u32 ncols, u64 nleaves,
+__global__ __launch_bounds__(HASH_THREADS, 5) void k_hash_leaves_absorb(const u64 *__restrict__ data, u64 col_stride, u32 ncols, u64 nleaves,
                                                                       u64 *__restrict__ state, u32 first, u32 last, u64 *__restrict__ digests,
                                                                       const u64 *__restrict__ rc) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +114,7 @@ __global__ __launch_bounds__(HASH_THREADS) void k_hash_leaves_absorb(const u64 *
   }
 }
 
-__global__ __launch_bounds__(HASH_THREADS) void k_hash_ext_leaves(const u64 *__restrict__ p0, const u64 *__restrict__ p1, u32 arity,
+__global__ __launch_bounds__(HASH_THREADS, 5) void k_hash_ext_leaves(const u64 *__restrict__ p0, const u64 *__restrict__ p1, u32 arity,
                                                                    u64 nleaves, u64 *__restrict__ digests,
                                                                    const u64 *__restrict__ rc) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,6 +281,10 @@ static inline unsigned blocks_for(u64 n, unsigned threads) { return (unsigned)((
 void launch_poseidon_permute_batch(hipStream_t s, const u64 *in, u64 *out, size_t count, const u64 *rc) {
   if (!count) return;
   hipLaunchKernelGGL(k_poseidon_permute_batch, dim3(blocks_for(count, HASH_THREADS)), dim3(HASH_THREADS), 0, s, in, out, count, rc);
+}
+void launch_field_mul(hipStream_t s, const u64 *a, const u64 *b, u64 *out, size_t count, u32 op) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_field_mul, dim3(blocks_for(count, HASH_THREADS)), dim3(HASH_THREADS), 0, s, a, b, out, count, op);
 }
 void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col_stride, u32 leaf_len, u64 nleaves, u64 *digests,
                         const u64 *rc) {

@@ -263,7 +263,6 @@ void stage_gate_programs(const std::vector<uint32_t> &code, std::vector<GateDev>
 // first to last; acc is the Horner chain with 1 / alpha (rescaled by the caller), as for every EMIT_FORWARD gate.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, u64 *lds, u32 T, u32 tid, QEmit &emit) {
-  const PosK k = pos_consts();
   const_as<u64> rc = konst(a.rc);
   // the constraints come first to last: constraint j has the weight alpha^j (QTerms; no 1 / alpha, no rescaling)
   QEmit &E = emit;
@@ -302,11 +301,11 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
   for (u32 r = 0; r < POS_FULL_HALF; r++, round++) {
     if (r) constrain12(29 + 12 * (r - 1));
 #pragma unroll
-    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j], k);
+    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j]);
     u64 nxt[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) nxt[j] = rc[(round + 1) * 12 + j];
-    pos_mds_h(lo, hi, nxt, k);
+    pos_mds_h(lo, hi, nxt);
   }
   // partial rounds, three at a time as in the hash kernels (poseidon.hpp pos_partial3_core): element 0 after every round is
   // emitted against the gate's S-box wire and the round continues from the wire.  The 22 S-box wires are fetched in groups of
@@ -329,30 +328,30 @@ __device__ __forceinline__ void q_poseidon_native(const QuotientArgs &a, u64 i, 
   for (u32 g = 0; g < POS_GROUPS; g++, r += POS_GROUP, round += POS_GROUP) {
     if (r % QUOTIENT_STAGE == 0) stage_sbox_wires(r);
     constrain0(r, lo[0], hi[0]);
-    pos_partial3_core(lo, hi, &rc[POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g], k, [&](int i, u32 &ul, u32 &uh) {
+    pos_partial3_core(lo, hi, &rc[POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g], [&](int i, u32 &ul, u32 &uh) {
       constrain0(r + i, ul, uh);
-      pos_sbox_h(ul, uh, k);
+      pos_sbox_h(ul, uh);
     });
   }
 #pragma unroll 1
   for (; r < POS_PARTIAL; r++, round++) {  // the round the groups leave over
     if (r % QUOTIENT_STAGE == 0) stage_sbox_wires(r);
     constrain0(r, lo[0], hi[0]);
-    pos_sbox_h(lo[0], hi[0], k);
+    pos_sbox_h(lo[0], hi[0]);
     u64 nxt[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) nxt[j] = rc[(round + 1) * 12 + j];
-    pos_mds_h(lo, hi, nxt, k);
+    pos_mds_h(lo, hi, nxt);
   }
 #pragma unroll 1
   for (u32 r = 0; r < POS_FULL_HALF; r++, round++) {
     constrain12(87 + 12 * r);
 #pragma unroll
-    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j], k);
+    for (int j = 0; j < 12; j++) pos_sbox_h(lo[j], hi[j]);
     u64 nxt[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) nxt[j] = round + 1 < POS_ROUNDS ? rc[(round + 1) * 12 + j] : 0;
-    pos_mds_h(lo, hi, nxt, k);
+    pos_mds_h(lo, hi, nxt);
   }
   u64 out[12];
 #pragma unroll

@@ -234,48 +234,41 @@ LCP2_HD void pos_permute_grouped_portable(u64 s[12], const u64 *__restrict__ rc)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---------------------------------------------------------------------------------------------------------
-// gfx950 form.  Measured (tools/ubench): VOP3 integer ops ~4.4 cycles per wave-instruction, VOP2 (add/sub with
-// carry through vcc, cndmask) ~2.7, and v_mad_u64_u32 is a VOP3 op like any other.  So the state is kept as
-// 32-bit halves, products are built from v_mad_u64_u32 and carry chains run through vcc in VOP2 encodings; the
-// compiler's own lowering of a 64x64 multiply + reduction is 27 instructions, this one is 17.  hipcc pads nothing
-// inside an asm string, so the wait states it emits itself for the same pairs on gfx950 (a VALU write of vcc -> any
-// VALU read of it: 2) are written out as s_nop 1 here; tools/check_hazards.py checks the built library.
+// gfx950 form.  Measured (tools/ubench): every VOP3-encoded or vcc-touching integer op (v_mad_u64_u32, add / sub with carry,
+// v_cndmask) costs ~4.3 cycles per wave-instruction, plain 32-bit VOP1/VOP2 ops ~2.5.  So the state is kept as 32-bit halves,
+// products and conditional corrections are v_mad_u64_u32 / v_mad_i64_i32 (gl_mul_halves, gl64.hpp: 12 + 2 moves per multiply; the
+// compiler's own lowering of a 64x64 multiply + reduction is 27).  hipcc pads nothing inside an asm string, so the wait states it
+// emits itself for the same pairs on gfx950 (a VALU write of vcc -> any VALU read of it: 2) are written out as s_nop 1 here;
+// tools/check_hazards.py checks the built library.
 // All values are lazy (any u64 congruent to the element); the final state is canonicalised.
 
-// the select constants of gl_mul_halves_k / pos_fold_h, made opaque to the compiler so that they are materialised once per
-// permutation and not rematerialised (a v_mov per use would cost what the VOP2 select saves)
-struct PosK { u32 one, ones; };
-__device__ __forceinline__ PosK pos_consts() {
-  PosK k;
-  asm volatile("v_mov_b32 %0, 1\n\tv_mov_b32 %1, -1" : "=v"(k.one), "=v"(k.ones));
-  return k;
-}
-
-__device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1, const PosK k) {
+__device__ __forceinline__ void pos_sbox_h(u32 &x0, u32 &x1) {
   u32 a0, a1, b0, b1, c0, c1;
-  gl_mul_halves_k(x0, x1, x0, x1, a0, a1, k.one, k.ones);  // x^2
-  gl_mul_halves_k(a0, a1, a0, a1, b0, b1, k.one, k.ones);  // x^4
-  gl_mul_halves_k(x0, x1, a0, a1, c0, c1, k.one, k.ones);  // x^3
-  gl_mul_halves_k(c0, c1, b0, b1, x0, x1, k.one, k.ones);  // x^7
+  gl_mul_halves(x0, x1, x0, x1, a0, a1);  // x^2
+  gl_mul_halves(a0, a1, a0, a1, b0, b1);  // x^4
+  gl_mul_halves(x0, x1, a0, a1, c0, c1);  // x^3
+  gl_mul_halves(c0, c1, b0, b1, x0, x1);  // x^7
 }
 
 // al + ah * 2^32 (al, ah < 2^42) -> lazy 64-bit value:  t = al + ah_hi * (2^64 mod p) ;  v = t + (ah_lo << 32), on carry += 2^32 - 1
-__device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1, const PosK k) {
-  const u64 t = (u64)(u32)(ah >> 32) * 0xFFFFFFFFu + al;
-  const u32 t0 = (u32)t, t1 = (u32)(t >> 32), ah0 = (u32)ah;
-  u32 e;
-  asm("v_add_co_u32 %1, vcc, %4, %5\n\t"
+// (as a multiply-add of the carry: v < 2^43 after a wrap, so no second carry)
+__device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1) {
+  u64 t = (u64)(u32)(ah >> 32) * 0xFFFFFFFFu + al;
+  u32 t1 = (u32)(t >> 32), c;
+  asm("v_add_co_u32 %0, vcc, %0, %2\n\t"
       "s_nop 1\n\t"
-      "v_cndmask_b32_e32 %2, 0, %6, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %3, %2\n\t"
-      "s_nop 1\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(r0), "=&v"(r1), "=&v"(e) : "v"(t0), "v"(t1), "v"(ah0), "v"(k.ones) : "vcc");
+      "v_cndmask_b32_e64 %1, 0, 1, vcc"
+      : "+v"(t1), "=&v"(c) : "v"((u32)ah) : "vcc");
+  t = ((u64)t1 << 32) | (u32)t;
+  u64 q;
+  asm("v_mad_u64_u32 %0, vcc, %1, -1, %2" : "=v"(q) : "v"(c), "v"(t) : "vcc");
+  r0 = (u32)q;
+  r1 = (u32)(q >> 32);
 }
 
 // state <- MDS(state) + add[0..12) ; add = the next round's constants (or nullptr): the constants ride in the
 // initial value of the accumulators, so the add-round-constant layer costs nothing.
-__device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add, const PosK k) {
+__device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u32 nl[12], nh[12];
 #pragma unroll
@@ -288,7 +281,7 @@ __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__r
       ah += (u64)hi[(i + r) % 12] * C[i];
     }
     if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-    pos_fold_h(al, ah, nl[r], nh[r], k);
+    pos_fold_h(al, ah, nl[r], nh[r]);
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
@@ -299,17 +292,17 @@ __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__r
 // leaves as the S-box output that enters the following round - the permutation raises it to the 7th power, the PoseidonGate
 // evaluator of the quotient (kernels_prover.hip) emits its difference to the gate's S-box wire and continues from the wire.
 template <class Consts /* pointer to the 14 constants, any address space */, class NextW>
-__device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts kc, const PosK k, NextW next_w) {
+__device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts kc, NextW next_w) {
   constexpr PosPartialTables T = pos_partial_tables();
   u32 w0l = lo[0], w0h = hi[0], w1l, w1h, w2l, w2h;
-  pos_sbox_h(w0l, w0h, k);
+  pos_sbox_h(w0l, w0h);
   {
     const u64 c = kc[0];
     u64 al = (u32)c, ah = c >> 32;
 #pragma unroll
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.a[j]; ah += (u64)hi[1 + j] * T.a[j]; }
     al += (u64)w0l * T.m00; ah += (u64)w0h * T.m00;
-    pos_fold_h(al, ah, w1l, w1h, k);
+    pos_fold_h(al, ah, w1l, w1h);
     next_w(1, w1l, w1h);
   }
   {
@@ -319,7 +312,7 @@ __device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA[j]; ah += (u64)hi[1 + j] * T.aA[j]; }
     al += (u64)w0l * T.ab; ah += (u64)w0h * T.ab;
     al += (u64)w1l * T.m00; ah += (u64)w1h * T.m00;
-    pos_fold_h(al, ah, w2l, w2h, k);
+    pos_fold_h(al, ah, w2l, w2h);
     next_w(2, w2l, w2h);
   }
   u32 nl[12], nh[12];
@@ -331,7 +324,7 @@ __device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts
     al += (u64)w0l * T.aAb; ah += (u64)w0h * T.aAb;
     al += (u64)w1l * T.ab; ah += (u64)w1h * T.ab;
     al += (u64)w2l * T.m00; ah += (u64)w2h * T.m00;
-    pos_fold_h(al, ah, nl[0], nh[0], k);
+    pos_fold_h(al, ah, nl[0], nh[0]);
   }
 #pragma unroll
   for (int i = 0; i < 11; i++) {
@@ -342,18 +335,17 @@ __device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts
     al += (u64)w0l * T.A2b[i]; ah += (u64)w0h * T.A2b[i];
     al += (u64)w1l * T.Ab[i]; ah += (u64)w1h * T.Ab[i];
     al += (u64)w2l * T.b[i]; ah += (u64)w2h * T.b[i];
-    pos_fold_h(al, ah, nl[1 + i], nh[1 + i], k);
+    pos_fold_h(al, ah, nl[1 + i], nh[1 + i]);
   }
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
 }
-__device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ kc, const PosK k) {
-  pos_partial3_core(lo, hi, kc, k, [&](int, u32 &ul, u32 &uh) { pos_sbox_h(ul, uh, k); });
+__device__ __forceinline__ void pos_partial3_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ kc) {
+  pos_partial3_core(lo, hi, kc, [&](int, u32 &ul, u32 &uh) { pos_sbox_h(ul, uh); });
 }
 
 // rc: POS_RC_WORDS words (the 360 round constants, then the group constants of the partial rounds)
 __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restrict__ rc) {
-  const PosK k = pos_consts();
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) { u64 v = gl_add_nc(s[i], rc[i]); lo[i] = (u32)v; hi[i] = (u32)(v >> 32); }
@@ -361,25 +353,25 @@ __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restr
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
   }
 #pragma unroll 1
-  for (int g = 0; g < POS_GROUPS; g++, round += POS_GROUP) pos_partial3_h(lo, hi, rc + POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g, k);
+  for (int g = 0; g < POS_GROUPS; g++, round += POS_GROUP) pos_partial3_h(lo, hi, rc + POS_ROUNDS * POS_W + POS_GROUP_CONSTS * g);
 #pragma unroll 1
   for (; round < POS_FULL_HALF + POS_PARTIAL; round++) {
-    pos_sbox_h(lo[0], hi[0], k);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
+    pos_sbox_h(lo[0], hi[0]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF - 1; r++, round++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
-    pos_mds_h(lo, hi, rc + (round + 1) * 12, k);
+    for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+    pos_mds_h(lo, hi, rc + (round + 1) * 12);
   }
 #pragma unroll
-  for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i], k);
-  pos_mds_h(lo, hi, nullptr, k);
+  for (int i = 0; i < 12; i++) pos_sbox_h(lo[i], hi[i]);
+  pos_mds_h(lo, hi, nullptr);
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(((u64)hi[i] << 32) | lo[i]);
 }
@@ -392,7 +384,6 @@ __device__ __forceinline__ void pos_permute_gfx950(u64 s[12], const u64 *__restr
 // POS_COOP_MAX_NODES nodes.  v: element j of the state (any u64); returns the canonical output element j.
 __device__ __forceinline__ u64 pos_permute_coop(u64 v, u32 j, const u64 *__restrict__ rc /* LDS copy of the round constants */) {
   const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-  const PosK k = pos_consts();
   const u32 lane = __lane_id(), jj = j < 12 ? j : 0, base = lane - j;
   u32 src[12];
 #pragma unroll
@@ -410,27 +401,27 @@ __device__ __forceinline__ u64 pos_permute_coop(u64 v, u32 j, const u64 *__restr
       ah += (u64)vh * C[i];
     }
     if (j == 0) { al += (u64)lo * 8u; ah += (u64)hi * 8u; }
-    pos_fold_h(al, ah, lo, hi, k);
+    pos_fold_h(al, ah, lo, hi);
   };
   int round = 0;
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
     const u64 next = rc[(round + 1) * 12 + jj];
-    pos_sbox_h(lo, hi, k);
+    pos_sbox_h(lo, hi);
     mds(next);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_PARTIAL; r++, round++) {
     const u64 next = rc[(round + 1) * 12 + jj];
     u32 s0 = lo, s1 = hi;
-    pos_sbox_h(s0, s1, k);
+    pos_sbox_h(s0, s1);
     if (j == 0) { lo = s0; hi = s1; }
     mds(next);
   }
 #pragma unroll 1
   for (int r = 0; r < POS_FULL_HALF; r++, round++) {
     const u64 next = round + 1 < POS_ROUNDS ? rc[(round + 1) * 12 + jj] : 0;
-    pos_sbox_h(lo, hi, k);
+    pos_sbox_h(lo, hi);
     mds(next);
   }
   return gl_canon(((u64)hi << 32) | lo);

@@ -49,21 +49,19 @@ __device__ __forceinline__ void q_stage(const QuotientArgs &a, u32 cnt, const_as
 // fold per element, exactly the layer of the hash kernels (poseidon.hpp), the 12 constants riding in the accumulators.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void q_pmds(u64 *lds, u32 T, u32 tid, u32 dst, u32 src, const_as<u64> add) {
-  const PosK k = pos_consts();
   u32 lo[12], hi[12];
   u64 rc[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) rc[j] = add[j];
 #pragma unroll
   for (int j = 0; j < 12; j++) { const u64 v = lds[(src + j) * T + tid]; lo[j] = (u32)v; hi[j] = (u32)(v >> 32); }
-  pos_mds_h(lo, hi, rc, k);
+  pos_mds_h(lo, hi, rc);
 #pragma unroll
   for (int j = 0; j < 12; j++) lds[(dst + j) * T + tid] = gl_canon(((u64)hi[j] << 32) | lo[j]);
 }
 __device__ __forceinline__ u64 q_sbox(u64 x) {
-  const PosK k = pos_consts();
   u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-  pos_sbox_h(x0, x1, k);
+  pos_sbox_h(x0, x1);
   return gl_canon(((u64)x1 << 32) | x0);
 }
 #else  // host pass of hipcc: declarations only

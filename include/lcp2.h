@@ -109,6 +109,12 @@ const char *lcp2_last_error(lcp2_ctx *ctx);
  * (plonky2 hash/poseidon.rs).  in/out: [count][12]. */
 int lcp2_poseidon_permute_batch(lcp2_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, lcp2_mem mem);
 
+/* GoldilocksField multiplication on `count` operand pairs with the device multiply every kernel uses (plonky2_field
+ * goldilocks_field.rs `impl Mul`, reduce128): op 0: out[i] = a[i] * b[i]; op 1: out[i] = a[i]^7 (Poseidon's S-box, b unused and
+ * may be NULL).  Operands may be any uint64_t, results are canonical.  For tests: random operands reach the borrow branch of the
+ * reduction with probability 2^-32, crafted ones reach it at will. */
+int lcp2_field_mul_batch(lcp2_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count, uint32_t op, lcp2_mem mem);
+
 /* MerkleTree::new(leaves, cap_height) (plonky2 hash/merkle_tree.rs): leaves is
  * row-major [nleaves][leaf_len]; cap receives 2^cap_height digests of 4 elements. */
 int lcp2_merkle_cap(lcp2_ctx *ctx, const uint64_t *leaves, size_t nleaves, size_t leaf_len,

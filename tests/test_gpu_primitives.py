@@ -31,6 +31,52 @@ def test_poseidon_batch_parity(gpu_ctx, oracle):
     assert gpu_ctx.poseidon_permute_batch(np.zeros((0, 12), dtype=np.uint64)).shape == (0, 12)
 
 
+def _field_mul_operands(rng):
+    """operand pairs for every branch of the device multiply's reduction (gl64.hpp gl_mul_halves): with (hi : lo) = a * b,
+    the borrow of lo - (hi >> 32) needs lo < 2^32 - one pair in 2^32 at random, so b is solved for from a chosen lo"""
+    M = 1 << 64
+    edge = [0, 1, 2, 7, P - 2, P - 1, P, P + 1, M - 1, M - 2, 1 << 63, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+            0x00000001FFFFFFFF, 0xFFFFFFFF, 0x100000000, 0x8000000080000000, 0x7FFFFFFF7FFFFFFF, 0xFFFF0001, 0x11111111]
+    a = [x for x in edge for _ in edge]
+    b = [y for _ in edge for y in edge]
+    kinds = {"borrow": 0, "borrow_then_carry": 0, "low_word_only": 0}
+    for _ in range(6000):
+        x = int(rng.integers(0, M, dtype=np.uint64)) | 1
+        lo = int(rng.integers(0, 1 << int(rng.integers(1, 33))))  # the low 64 bits of the product, below 2^32
+        y = lo * pow(x, -1, M) % M
+        prod = x * y
+        assert prod % M == lo
+        hi = prod >> 64
+        if lo < (hi >> 32):
+            kinds["borrow"] += 1
+            t = (lo - (hi >> 32) - 0xFFFFFFFF) % M
+            kinds["borrow_then_carry"] += t + (hi & 0xFFFFFFFF) * 0xFFFFFFFF >= M
+        else:
+            kinds["low_word_only"] += 1
+        a.append(x); b.append(y)
+    assert min(kinds.values()) > 100, kinds
+    for _ in range(4000):  # hi < 2^32: no borrow, and hi_hi = 0 ; and the high halves alone
+        x, y = int(rng.integers(0, 1 << 48)), int(rng.integers(0, 1 << 48))
+        a.append(x); b.append(y)
+        a.append(x << 16 & (M - 1)); b.append(y << 32 & (M - 1))
+    r = rng.integers(0, M, size=(2, 20000), dtype=np.uint64)
+    return np.concatenate([np.array(a, dtype=np.uint64), r[0]]), np.concatenate([np.array(b, dtype=np.uint64), r[1]])
+
+
+def test_field_multiply_reaches_every_reduction_branch(gpu_ctx):
+    """the one multiply all kernels share, through the C ABI, against Python integers"""
+    rng = np.random.default_rng(2024)
+    a, b = _field_mul_operands(rng)
+    got = gpu_ctx.field_mul_batch(a, b)
+    want = np.array([int(x) * int(y) % P for x, y in zip(a, b)], dtype=np.uint64)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(hex(int(a[i])), hex(int(b[i])), hex(int(got[i])), hex(int(want[i]))) for i in bad[:4]]
+    got7 = gpu_ctx.field_mul_batch(a)
+    want7 = np.array([pow(int(x), 7, P) for x in a], dtype=np.uint64)
+    assert (got7 == want7).all()
+    assert gpu_ctx.field_mul_batch(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)).shape == (0,)
+
+
 @pytest.mark.parametrize("leaf_len", [1, 3, 4, 5, 8, 9, 16, 20, 32, 135])
 @pytest.mark.parametrize("log_leaves,cap_height", [(4, 4), (5, 4), (6, 0), (9, 4), (11, 2)])
 def test_merkle_cap_parity(gpu_ctx, oracle, leaf_len, log_leaves, cap_height):
