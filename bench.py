@@ -55,7 +55,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a full-rate wave64 VALU instruction issues in 2 cycles, 2.4 GHz -> 78.6 T lane-instructions/s
 VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9
 CLOCK_HZ = 2.4e9
-CENSUS = os.path.join(ROOT, "profiles", "r03_poseidon_census.json")  # tools/poseidon_census.py: VALU instructions per permutation as compiled
+CENSUS = os.path.join(ROOT, "profiles", "r04_poseidon_census.json")  # tools/poseidon_census.py: VALU instructions per permutation as compiled
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of the bench (tools/collect_profiles.sh)
 REFERENCE_MIX_PMC = os.path.join(ROOT, "profiles", "r04_reference_mix_k6.json")  # tools/k6_profile_summary.py: K6 kernel times and FETCH_SIZE of the reference gate set

@@ -106,7 +106,7 @@ def load_library():
         "lcp2_ctx_stream": (c.c_void_p, [c.c_void_p]),
         "lcp2_last_error": (c.c_char_p, [c.c_void_p]),
         "lcp2_poseidon_permute_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]),
-        "lcp2_field_mul_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int]),
+        "lcp2_field_op_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int]),
         "lcp2_merkle_cap": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_uint32, c.c_int, c.c_void_p]),
         "lcp2_ntt_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_int, c.c_uint64, c.c_int]),
         "lcp2_lde_batch": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint32, c.c_int]),
@@ -285,16 +285,18 @@ class Context:
         self._check(self.lib.lcp2_poseidon_permute_batch(self.handle, _ptr(s), _ptr(out), s.shape[0], MEM_HOST))
         return out
 
-    def field_mul_batch(self, a, b=None):
-        """a * b elementwise with the device multiply (b None: a^7, the Poseidon S-box); operands any u64, results canonical"""
+    FIELD_OPS = {"mul": 0, "pow7": 1, "add": 2, "sub": 3, "canon": 4, "add_lazy": 5, "sub_lazy": 6, "shl32_lazy": 24, "mul_u32": 25,
+                 **{"shl%d" % (12 * k): 16 + k for k in range(1, 8)}}
+
+    def field_op_batch(self, op, a, b=None):
+        """elementwise field arithmetic with the device functions of csrc/gl64.hpp (LCP2_FIELD_*); operands any u64, results canonical"""
         a = _np_u64(a).reshape(-1)
         out = np.empty_like(a)
-        if b is None:
-            self._check(self.lib.lcp2_field_mul_batch(self.handle, _ptr(a), None, _ptr(out), a.shape[0], 1, MEM_HOST))
-        else:
+        if b is not None:
             b = _np_u64(b).reshape(-1)
             assert a.shape == b.shape
-            self._check(self.lib.lcp2_field_mul_batch(self.handle, _ptr(a), _ptr(b), _ptr(out), a.shape[0], 0, MEM_HOST))
+        self._check(self.lib.lcp2_field_op_batch(self.handle, _ptr(a), _ptr(b) if b is not None else None, _ptr(out), a.shape[0],
+                                                 self.FIELD_OPS[op], MEM_HOST))
         return out
 
     def merkle_cap(self, leaves, cap_height):

@@ -93,7 +93,7 @@ struct ProfScope {
 
 // ---- kernel launch wrappers (device pointers, asynchronous on `s`) ----
 void launch_poseidon_permute_batch(hipStream_t s, const u64 *in, u64 *out, size_t count, const u64 *rc);
-void launch_field_mul(hipStream_t s, const u64 *a, const u64 *b, u64 *out, size_t count, u32 op);
+void launch_field_op(hipStream_t s, const u64 *a, const u64 *b, u64 *out, size_t count, u32 op);
 // leaf i, element c at  data[i * leaf_stride + c * col_stride]
 void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col_stride, u32 leaf_len, u64 nleaves,
                         u64 *digests, const u64 *rc);

@@ -32,23 +32,35 @@ __global__ __launch_bounds__(HASH_THREADS) void k_poseidon_permute_batch(const u
   for (int j = 0; j < 12; j++) out[i * 12 + j] = s[j];
 }
 
-// out = a * b (op 0) or a^7 (op 1: the Poseidon S-box as the hash kernels compute it), canonical; any u64 in.  The device multiply
-// of every kernel of the library (gl_mul_halves), exposed so that the tests can drive it with operands that reach the rare
-// branches of its reduction (a borrow in lo - hi_hi has probability 2^-32 on random operands).
-__global__ __launch_bounds__(HASH_THREADS) void k_field_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out,
-                                                             size_t count, u32 op) {
+// The device field arithmetic every kernel of the library shares (gl64.hpp), exposed so that the tests can drive it with operands
+// that reach the rare branches (a borrow in the multiply's lo - hi_hi has probability 2^-32 on random operands).  Results are
+// canonical; op as LCP2_FIELD_* of lcp2.h.
+__global__ __launch_bounds__(HASH_THREADS) void k_field_op(const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out,
+                                                            size_t count, u32 op) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-  const u64 x = a[i];
-  u32 r0 = (u32)x, r1 = (u32)(x >> 32);
-  if (op == 0) {
-    const u64 y = b[i];
-    gl_mul_halves((u32)x, (u32)(x >> 32), (u32)y, (u32)(y >> 32), r0, r1);
-  } else {
-    pos_sbox_h(r0, r1);
+  const u64 x = a[i], y = b ? b[i] : 0;
+  u64 r = 0;
+  switch (op) {
+    case LCP2_FIELD_MUL: r = gl_mul(x, y); break;
+    case LCP2_FIELD_POW7: { u32 r0 = (u32)x, r1 = (u32)(x >> 32); pos_sbox_h(r0, r1); r = gl_canon(((u64)r1 << 32) | r0); break; }
+    case LCP2_FIELD_ADD: r = gl_add(gl_canon(x), gl_canon(y)); break;
+    case LCP2_FIELD_SUB: r = gl_sub(gl_canon(x), gl_canon(y)); break;
+    case LCP2_FIELD_CANON: r = gl_canon(x); break;
+    case LCP2_FIELD_ADD_LAZY: r = gl_canon(gl_add_nc(x, gl_canon(y))); break;
+    case LCP2_FIELD_SUB_LAZY: r = gl_canon(gl_sub_nc(x, gl_canon(y))); break;
+    case LCP2_FIELD_SHL + 1: r = gl_shl<12>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 2: r = gl_shl<24>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 3: r = gl_shl<36>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 4: r = gl_shl<48>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 5: r = gl_shl<60>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 6: r = gl_shl<72>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 7: r = gl_shl<84>(gl_canon(x)); break;
+    case LCP2_FIELD_SHL + 8: r = gl_canon(gl_shl_nc<32>(x)); break;
+    case LCP2_FIELD_SHL + 9: r = gl_canon(gl_mul_u32_nc(x, (u32)y)); break;
   }
-  out[i] = gl_canon(((u64)r1 << 32) | r0);
+  out[i] = r;
 #endif
 }
 
@@ -282,9 +294,9 @@ void launch_poseidon_permute_batch(hipStream_t s, const u64 *in, u64 *out, size_
   if (!count) return;
   hipLaunchKernelGGL(k_poseidon_permute_batch, dim3(blocks_for(count, HASH_THREADS)), dim3(HASH_THREADS), 0, s, in, out, count, rc);
 }
-void launch_field_mul(hipStream_t s, const u64 *a, const u64 *b, u64 *out, size_t count, u32 op) {
+void launch_field_op(hipStream_t s, const u64 *a, const u64 *b, u64 *out, size_t count, u32 op) {
   if (!count) return;
-  hipLaunchKernelGGL(k_field_mul, dim3(blocks_for(count, HASH_THREADS)), dim3(HASH_THREADS), 0, s, a, b, out, count, op);
+  hipLaunchKernelGGL(k_field_op, dim3(blocks_for(count, HASH_THREADS)), dim3(HASH_THREADS), 0, s, a, b, out, count, op);
 }
 void launch_hash_leaves(hipStream_t s, const u64 *data, u64 leaf_stride, u64 col_stride, u32 leaf_len, u64 nleaves, u64 *digests,
                         const u64 *rc) {

@@ -214,15 +214,18 @@ extern "C" int lcp2_poseidon_permute_batch(lcp2_ctx *ctx, const uint64_t *in, ui
   return stage_out_finish(ctx, out, bytes, mem, so);
 }
 
-extern "C" int lcp2_field_mul_batch(lcp2_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count, uint32_t op, lcp2_mem mem) {
-  if (!ctx || op > 1 || (count && (!a || !out || (op == 0 && !b)))) return LCP2_E_INVALID;
+extern "C" int lcp2_field_op_batch(lcp2_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count, uint32_t op, lcp2_mem mem) {
+  const bool binary = op == LCP2_FIELD_MUL || op == LCP2_FIELD_ADD || op == LCP2_FIELD_SUB || op == LCP2_FIELD_ADD_LAZY ||
+                      op == LCP2_FIELD_SUB_LAZY || op == LCP2_FIELD_SHL + 9;
+  const bool unary = op == LCP2_FIELD_POW7 || op == LCP2_FIELD_CANON || (op > LCP2_FIELD_SHL && op <= LCP2_FIELD_SHL + 8);
+  if (!ctx || !(binary || unary) || (count && (!a || !out || (binary && !b)))) return LCP2_E_INVALID;
   LCP2_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * sizeof(u64);
   Staged sa, sb, so;
   LCP2_TRY(stage_in(ctx, a, bytes, mem, sa));
-  if (op == 0) LCP2_TRY(stage_in(ctx, b, bytes, mem, sb));
+  if (binary) LCP2_TRY(stage_in(ctx, b, bytes, mem, sb));
   LCP2_TRY(stage_out_alloc(ctx, out, bytes, mem, so));
-  launch_field_mul(ctx->stream, sa.d, op == 0 ? sb.d : nullptr, so.d, count, op);
+  launch_field_op(ctx->stream, sa.d, binary ? sb.d : nullptr, so.d, count, op);
   LCP2_HIP(ctx, hipGetLastError());
   return stage_out_finish(ctx, out, bytes, mem, so);
 }

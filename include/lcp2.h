@@ -109,11 +109,22 @@ const char *lcp2_last_error(lcp2_ctx *ctx);
  * (plonky2 hash/poseidon.rs).  in/out: [count][12]. */
 int lcp2_poseidon_permute_batch(lcp2_ctx *ctx, const uint64_t *in, uint64_t *out, size_t count, lcp2_mem mem);
 
-/* GoldilocksField multiplication on `count` operand pairs with the device multiply every kernel uses (plonky2_field
- * goldilocks_field.rs `impl Mul`, reduce128): op 0: out[i] = a[i] * b[i]; op 1: out[i] = a[i]^7 (Poseidon's S-box, b unused and
- * may be NULL).  Operands may be any uint64_t, results are canonical.  For tests: random operands reach the borrow branch of the
- * reduction with probability 2^-32, crafted ones reach it at will. */
-int lcp2_field_mul_batch(lcp2_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count, uint32_t op, lcp2_mem mem);
+/* GoldilocksField arithmetic on `count` operands with the device functions every kernel uses (plonky2_field goldilocks_field.rs
+ * `impl Add / Sub / Mul`, reduce128; csrc/gl64.hpp).  Operands may be any uint64_t, results are canonical; b is unused (NULL allowed)
+ * by the unary operations.  For tests: random operands reach the borrow branch of the multiply's reduction with probability
+ * 2^-32, crafted ones reach it at will. */
+enum {
+  LCP2_FIELD_MUL = 0,       /* a * b */
+  LCP2_FIELD_POW7 = 1,      /* a^7: Poseidon's S-box as the hash kernels compute it */
+  LCP2_FIELD_ADD = 2,       /* canonical add of the canonicalised operands */
+  LCP2_FIELD_SUB = 3,       /* canonical subtract of the canonicalised operands */
+  LCP2_FIELD_CANON = 4,     /* a mod p */
+  LCP2_FIELD_ADD_LAZY = 5,  /* the lazy add (a: any value, b canonicalised), result canonicalised */
+  LCP2_FIELD_SUB_LAZY = 6,  /* the lazy subtract */
+  LCP2_FIELD_SHL = 16       /* LCP2_FIELD_SHL + k, k = 1..7: a * 2^(12 k), the NTT's register twiddles; + 8: the lazy a * 2^32;
+                               + 9: a * (uint32_t)b, the multiply by a 32-bit constant */
+};
+int lcp2_field_op_batch(lcp2_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count, uint32_t op, lcp2_mem mem);
 
 /* MerkleTree::new(leaves, cap_height) (plonky2 hash/merkle_tree.rs): leaves is
  * row-major [nleaves][leaf_len]; cap receives 2^cap_height digests of 4 elements. */

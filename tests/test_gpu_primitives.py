@@ -63,18 +63,31 @@ def _field_mul_operands(rng):
     return np.concatenate([np.array(a, dtype=np.uint64), r[0]]), np.concatenate([np.array(b, dtype=np.uint64), r[1]])
 
 
-def test_field_multiply_reaches_every_reduction_branch(gpu_ctx):
-    """the one multiply all kernels share, through the C ABI, against Python integers"""
+def test_field_arithmetic_reaches_every_reduction_branch(gpu_ctx):
+    """the arithmetic all kernels share (csrc/gl64.hpp), through the C ABI, against Python integers"""
     rng = np.random.default_rng(2024)
     a, b = _field_mul_operands(rng)
-    got = gpu_ctx.field_mul_batch(a, b)
-    want = np.array([int(x) * int(y) % P for x, y in zip(a, b)], dtype=np.uint64)
-    bad = np.nonzero(got != want)[0]
-    assert bad.size == 0, [(hex(int(a[i])), hex(int(b[i])), hex(int(got[i])), hex(int(want[i]))) for i in bad[:4]]
-    got7 = gpu_ctx.field_mul_batch(a)
-    want7 = np.array([pow(int(x), 7, P) for x in a], dtype=np.uint64)
-    assert (got7 == want7).all()
-    assert gpu_ctx.field_mul_batch(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)).shape == (0,)
+    ints = lambda v: [int(x) for x in v]
+    A, B = ints(a), ints(b)
+
+    def check(op, want, second=True):
+        got = gpu_ctx.field_op_batch(op, a, b if second else None)
+        w = np.array(want, dtype=np.uint64)
+        bad = np.nonzero(got != w)[0]
+        assert bad.size == 0, (op, [(hex(A[i]), hex(B[i]), hex(int(got[i])), hex(int(w[i]))) for i in bad[:4]])
+
+    check("mul", [x * y % P for x, y in zip(A, B)])
+    check("pow7", [pow(x, 7, P) for x in A], second=False)
+    check("add", [(x + y) % P for x, y in zip(A, B)])
+    check("sub", [(x - y) % P for x, y in zip(A, B)])
+    check("canon", [x % P for x in A], second=False)
+    check("add_lazy", [(x + y) % P for x, y in zip(A, B)])
+    check("sub_lazy", [(x - y) % P for x, y in zip(A, B)])
+    for k in range(1, 8):
+        check("shl%d" % (12 * k), [(x << (12 * k)) % P for x in A], second=False)
+    check("shl32_lazy", [(x << 32) % P for x in A], second=False)
+    check("mul_u32", [x * (y & 0xFFFFFFFF) % P for x, y in zip(A, B)])
+    assert gpu_ctx.field_op_batch("mul", np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)).shape == (0,)
 
 
 @pytest.mark.parametrize("leaf_len", [1, 3, 4, 5, 8, 9, 16, 20, 32, 135])
