@@ -3,7 +3,7 @@
 #   rocprofv3 kernel trace + stats of bench.py (headline only: the 2^22-row real-gadget circuit, data.prove(pw) in-process), FETCH_SIZE and
 #   WRITE_SIZE PMC passes of the same command (separate, as MI355X_MICROARCH.md prescribes), SQ counters of a 2^22 proof, kernel trace of the
 #   light-client step (lc_prover) and its idle-time summary, the reference gate set (tools/reference_mix_probe.py) under the same two passes,
-#   the per-rank compute of a sharded proof, the sharded code path over a 1-rank RCCL group, the oracle's 2^20 timing sample, the plain bench line.
+#   the multiply micro-benchmark (tools/ubench/mulchain.hip), the per-rank compute of a sharded proof, the sharded code path over a 1-rank RCCL group, the oracle's 2^20 timing sample, the plain bench line.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=$1
 mkdir -p $out
@@ -26,6 +26,8 @@ for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 
 for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --chunked --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal_chunked.log || exit 1; done && \
 python3 bench.py --force-sharded --no-cpu-baseline --no-real-gadgets --no-synthetic > $out/bench_force_sharded.json 2> $out/bench_force_sharded.err && \
 python3 tools/cpu_baseline_scaling.py 20 > $out/cpu_baseline_scaling.json 2> $out/cpu_baseline_scaling.err && \
-python3 bench.py > $out/bench.json 2> $out/bench.err
+python3 bench.py > $out/bench.json 2> $out/bench.err && \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/mulchain tools/ubench/mulchain.hip > /dev/null 2>&1 && \
+for w in 2 4 8; do /tmp/mulchain $w || exit 1; done > $out/ubench_mulchain.txt
 echo "collect rc=$?"
 find $out -name "*.csv" | head -40

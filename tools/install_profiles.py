@@ -28,6 +28,8 @@ shutil.copy(f"{src}/kt/kt_kernel_stats.csv", f"{p}/{tag}_full_proof_kernel_stats
 shutil.copy(f"{src}/lc/lc_kernel_stats.csv", f"{p}/{tag}_lc_step_kernel_stats.csv")
 if os.path.exists(f"{src}/ubench.txt"):
     shutil.copy(f"{src}/ubench.txt", f"{p}/{tag}_ubench_int_rates.txt")
+if os.path.exists(f"{src}/ubench_mulchain.txt"):
+    shutil.copy(f"{src}/ubench_mulchain.txt", f"{p}/{tag}_ubench_mulchain.txt")
 if os.path.exists(f"{src}/sharded_rehearsal.log"):
     shutil.copy(f"{src}/sharded_rehearsal.log", f"{p}/{tag}_sharded_rehearsal.log")
 if os.path.exists(f"{src}/sharded_rehearsal_chunked.log"):

@@ -1,8 +1,12 @@
-// Micro-benchmark: the 64 x 64 -> 64 Goldilocks multiply of the Poseidon S-box (csrc/gl64.hpp gl_mul_halves_k) against a CHAINED
-// form of its 128-bit product: the partial products ride in the 64-bit addend of v_mad_u64_u32 (p = a0 b0; t = a0 b1 + p_hi;
-// u = a1 b0 + t (carry c); v = a1 b1 + (u_hi + c 2^32)), which replaces the three carry-chain additions of the product by register moves.
-// 12 independent chains of dependent multiplies per lane (x <- x * y, the shape of a full round's S-box layer), results compared.
-//     hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mulchain tools/ubench/mulchain.hip && tools/ubench/mulchain
+// Micro-benchmark of the 64 x 64 -> 64 Goldilocks multiply (csrc/gl64.hpp gl_mul_halves), four forms, results compared:
+//   current   the carry-chain form of rounds 2-4: four v_mad_u64_u32, the 128-bit product summed by add-with-carry, the reduction on carry
+//             chains (17 instructions)
+//   chained   the partial products ride in the 64-bit addend of v_mad_u64_u32 (p = a0 b0; t = a0 b1 + p_hi; u = a1 b0 + t (carry c);
+//             v = a1 b1 + (u_hi + c 2^32)): the three add-with-carry of the product become register moves
+//   chained2  + both conditional corrections of the reduction as multiply-adds of a selected factor (selects in VOP2, constants in VGPRs)
+//   chained3  + selects in VOP3 with inline constants, no constant VGPRs: what gl_mul_halves is now (12 instructions + 2 moves)
+// 12 independent chains of dependent multiplies per lane (x <- x * y, the shape of a full round's S-box layer).
+//     hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mulchain tools/ubench/mulchain.hip && tools/ubench/mulchain [waves per SIMD: 1 2 3 4 8]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
