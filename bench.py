@@ -450,7 +450,15 @@ def cpu_baseline(m, ctx, sample_bits, degree_bits):
     lg_s, lg_d = sample_bits + params.rate_bits, degree_bits + params.rate_bits
     rows = float(1 << (degree_bits - sample_bits))
     est = rows * ((dt - t_ntt) + t_ntt * lg_d / lg_s)
-    return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port", "gpu_proof_equal": equal,
+    full = None
+    try:  # the one measured full-size point (tools/parity_full_size.py on the GPU box's host, committed: not of this run)
+        f = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_full_size.json")))
+        full = {"source": "profiles/r04_parity_full_size.json (tools/parity_full_size.py, a separate run: the oracle's prove() at 2^%d rows on %d threads, "
+                          "the GPU proof of the same witness compared word for word)" % (f["degree_bits"], f["threads"]),
+                "oracle_prove_s": f["oracle_prove_s"], "proofs_per_hour": 3600.0 / f["oracle_prove_s"], "gpu_proof_equal": f["gpu_proof_equal"]}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port", "gpu_proof_equal": equal, "measured_at_full_size": full,
             "sample": "oracle prove() of plonky2's gate set at 2^%d rows: %.2f s on %d OpenMP threads, of which transforms ~%.2f s; scaled to 2^%d rows "
                       "(transforms x%d x %d/%d for n log n, the rest x%d): %.0f s per proof; the GPU proved the same sample: proofs %s word for word"
                       % (sample_bits, dt, threads, t_ntt, degree_bits, int(rows), lg_d, lg_s, int(rows), est, "EQUAL" if equal else "DIFFER")}

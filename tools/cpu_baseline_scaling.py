@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py's cpu_baseline scales a 2^18-row oracle proof to 2^22 rows with a model (transforms as n log n, the rest linearly).
 This measures the oracle at 2^18 AND at 2^20 (about 2.5 minutes on the box's 32 threads: too long for the default bench run), applies
-the model to the 2^18 sample and writes both next to each other: profiles/r04_cpu_baseline_scaling.json.
+the model to the 2^18 sample and writes both next to each other: profiles/r04_cpu_baseline_scaling.json.  The GPU proves both samples
+too and the proofs are compared word for word (`gpu_proof_equal`): whole-proof parity at 2^20 rows, which the default bench run stops
+short of (2^18).
     python3 tools/cpu_baseline_scaling.py [big_bits=20] > gpurun_out/cpu_scaling.json"""
 import ctypes
 import json
@@ -22,6 +24,7 @@ omp = ctypes.CDLL("libgomp.so.1")
 threads = min(32, omp.omp_get_max_threads())
 omp.omp_set_num_threads(threads)
 out = {"threads": threads, "samples": {}}
+ctx = m.Context(0)
 for bits in (18, big):
     params = m.standard_params(bits, 4)
     circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1, small_values=True)
@@ -31,6 +34,13 @@ for bits in (18, big):
     dt = time.perf_counter() - t0
     assert oc.verify(proof, pis) == 0
     oc.close()
+    data = m.CircuitData.build(ctx, circ)
+    t0 = time.perf_counter()
+    gpu_proof = data.prove(wires, pis)
+    gpu_dt = time.perf_counter() - t0
+    equal = bool((gpu_proof == proof).all())
+    data.close()
+    del gpu_proof, proof
     n = 1 << bits
     cols = np.ascontiguousarray(wires % np.uint64(m.GOLDILOCKS_P))
     lde = np.zeros((cols.shape[0], n << params.rate_bits), dtype=np.uint64)
@@ -38,8 +48,9 @@ for bits in (18, big):
     L.orc_lde_batch(oracle_lib.vp(cols), cols.shape[0], n, params.rate_bits, 7, oracle_lib.vp(lde))
     t_ntt = min(1.4 * (time.perf_counter() - t0), 0.9 * dt)
     del lde, cols, wires, circ
-    out["samples"][str(bits)] = {"prove_s": dt, "transforms_s": t_ntt}
-    print("2^%d rows: %.2f s (transforms ~%.2f s)" % (bits, dt, t_ntt), file=sys.stderr, flush=True)
+    out["samples"][str(bits)] = {"prove_s": dt, "transforms_s": t_ntt, "gpu_proof_equal": equal, "gpu_prove_from_host_witness_s": gpu_dt}
+    print("2^%d rows: %.2f s (transforms ~%.2f s); GPU proof %s" % (bits, dt, t_ntt, "EQUAL" if equal else "DIFFERS"), file=sys.stderr, flush=True)
+    assert equal, "GPU proof differs from the oracle proof at 2^%d rows" % bits
 s = out["samples"]["18"]
 rows = float(1 << (big - 18))
 model = rows * ((s["prove_s"] - s["transforms_s"]) + s["transforms_s"] * (big + 3) / (18 + 3))
