@@ -451,11 +451,17 @@ def cpu_baseline(m, ctx, sample_bits, degree_bits):
     rows = float(1 << (degree_bits - sample_bits))
     est = rows * ((dt - t_ntt) + t_ntt * lg_d / lg_s)
     full = None
-    try:  # the one measured full-size point (tools/parity_full_size.py on the GPU box's host, committed: not of this run)
+    try:  # the measured full-size points (separate runs on the GPU box's host, committed: not of this run)
         f = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_full_size.json")))
-        full = {"source": "profiles/r04_parity_full_size.json (tools/parity_full_size.py, a separate run: the oracle's prove() at 2^%d rows on %d threads, "
-                          "the GPU proof of the same witness compared word for word)" % (f["degree_bits"], f["threads"]),
-                "oracle_prove_s": f["oracle_prove_s"], "proofs_per_hour": 3600.0 / f["oracle_prove_s"], "gpu_proof_equal": f["gpu_proof_equal"]}
+        full = {"plonky2_gate_set": {
+            "source": "profiles/r04_parity_full_size.json (tools/parity_full_size.py: the oracle's prove() at 2^%d rows on %d threads, the GPU proof of the same "
+                      "witness compared word for word)" % (f["degree_bits"], f["threads"]),
+            "oracle_prove_s": f["oracle_prove_s"], "proofs_per_hour": 3600.0 / f["oracle_prove_s"], "gpu_proof_equal": f["gpu_proof_equal"]}}
+        g = json.load(open(os.path.join(ROOT, "profiles", "r04_real_gadget_parity.json")))["headline_circuit_2p22"]
+        full["headline_circuit"] = {
+            "source": "profiles/r04_real_gadget_parity.json (LCP2_ORACLE_PROVE_ALL=1 tests/cpp/test_gadgets gpu %s: the circuit of this line's headline, 2^%d rows, oracle on %d "
+                      "threads, GPU proof compared word for word)" % (g["test"], g["degree_bits"], g["threads"]),
+            "oracle_prove_s": g["oracle_prove_s"], "proofs_per_hour": 3600.0 / g["oracle_prove_s"], "gpu_proof_equal": g["gpu_proof_equal"]}
     except (OSError, KeyError, ValueError):
         pass
     return {"value": 3600.0 / est, "unit": "proofs/hr", "cores": threads, "kind": "port", "gpu_proof_equal": equal, "measured_at_full_size": full,

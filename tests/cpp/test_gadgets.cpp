@@ -65,7 +65,7 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
   static_assert(sizeof(orc_gate) == sizeof(lcp2_gate), "gate layouts must agree");
   memcpy(og.data(), D.gates.data(), og.size() * sizeof(orc_gate));
   // the oracle's build() (constants/sigmas commitment) is only needed when the oracle proves or verifies
-  const bool need_built = !g_skip_oracle_prove || (g_gpu && !getenv("LCP2_SKIP_ORACLE_BUILD"));
+  const bool need_built = !g_skip_oracle_prove || getenv("LCP2_ORACLE_PROVE_ALL") || (g_gpu && !getenv("LCP2_SKIP_ORACLE_BUILD"));
   orc_circuit *oc = (need_built ? orc_circuit_new : orc_circuit_new_unbuilt)(
       &op, D.constants_sigmas.data(), D.k_is.data(), D.num_selectors, og.data(), (uint32_t)og.size(), D.code.data(), D.code.size(),
       D.imm.data(), D.imm.size(), D.num_public_inputs);
@@ -77,10 +77,15 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     throw std::runtime_error("gate constraints violated: " + std::to_string(nbad) + " (first: row " + std::to_string(bad[0]) + " constraint " + std::to_string(bad[1]) + ")");
   }
   std::vector<uint64_t> oproof;
-  if (!g_skip_oracle_prove) {
+  // LCP2_ORACLE_PROVE_ALL=1: the oracle also proves the circuits the suite leaves to the GPU run (2^19 rows and up: minutes of CPU
+  // time each), so that their GPU proofs are compared word for word too (run once per round, profiles/r04_real_gadget_parity.log)
+  const bool oracle_proves = !g_skip_oracle_prove || getenv("LCP2_ORACLE_PROVE_ALL");
+  if (oracle_proves) {
+    const auto tp = std::chrono::steady_clock::now();
     oproof.resize(orc_proof_words(&op));
     orc_prove(oc, wires.data(), pis.data(), oproof.data());
     if (orc_verify(oc, oproof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the oracle proof");
+    if (g_skip_oracle_prove) printf("oracle proved in %lld s (degree_bits %u)\n", (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - tp).count(), data.degree_bits());
   }
   if (g_gpu) {
     data.attach_gpu(g_ctx);
@@ -99,6 +104,7 @@ static void prove_and_verify(CircuitData &data, const PartialWitness &witness) {
     printf("proved in %lldms (degree_bits %u)\n", (long long)ms, data.degree_bits());
     data.verify(proof);  // assert!(data.verify(proof).is_ok())
     if (!oproof.empty() && proof.proof != oproof) throw std::runtime_error("GPU proof differs from the oracle proof");
+    if (!oproof.empty() && g_skip_oracle_prove) printf("GPU proof equals the oracle proof word for word (%zu words, degree_bits %u)\n", oproof.size(), data.degree_bits());
     if (need_built && orc_verify(oc, proof.proof.data(), pis.data()) != 0) throw std::runtime_error("oracle verifier rejected the GPU proof");
     {
       // the independent verifier at ANY size: the oracle's verifier from digest + constants/sigmas cap alone (no oracle build()),

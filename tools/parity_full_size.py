@@ -2,7 +2,9 @@
 """Whole-proof parity at the headline size: the CPU oracle (oracle/, 32 OpenMP threads, ~10 minutes of prove() at 2^22 rows plus its
 build()) and the GPU prove the same 2^22-row circuit of plonky2's gate set from the same witness, and the two proofs are compared word
 for word.  Too long for the test-suite and for bench.py (whose cpu_baseline leg does the same at 2^18); run once per round on the GPU box:
-    python3 tools/parity_full_size.py [bits=22] > gpurun_out/parity_full_size.json
+    python3 tools/parity_full_size.py [bits=22] [plonky2|reference-mix] > gpurun_out/parity_full_size.json
+`reference-mix`: the reference's own gate set (u32_gates.reference_mix_circuit: plonky2_u32 / comparison gates on the GENERATED native
+evaluators of the device, interpreted gate programs in the oracle).
 A heartbeat line goes to stderr every minute (the box takes a silent command for hung)."""
 import ctypes
 import json
@@ -19,6 +21,7 @@ import eth_lc_plonky2_amd as m  # noqa: E402
 import oracle_lib  # noqa: E402
 
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+workload = sys.argv[2] if len(sys.argv) > 2 else "plonky2"
 phase = {"name": "start", "t0": time.perf_counter()}
 
 
@@ -33,11 +36,15 @@ L = oracle_lib.load()
 omp = ctypes.CDLL("libgomp.so.1")
 threads = min(32, omp.omp_get_max_threads())
 omp.omp_set_num_threads(threads)
-out = {"degree_bits": bits, "threads": threads}
+out = {"degree_bits": bits, "threads": threads, "workload": workload}
 phase["name"] = "circuit description"
 t0 = time.perf_counter()
-params = m.standard_params(bits, 4)
-circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1, small_values=True)
+if workload == "reference-mix":
+    params = m.standard_params(bits, 5)
+    circ, wires, pis = m.u32_gates.reference_mix_circuit(params, seed=1, native=True, small_values=True)
+else:
+    params = m.standard_params(bits, 4)
+    circ, wires, pis = m.circuit.synthetic_circuit(params, seed=1, small_values=True)
 out["description_s"] = time.perf_counter() - t0
 # the GPU first (seconds): if the oracle run is cut short the GPU side is still on record
 phase["name"] = "GPU build + prove"
