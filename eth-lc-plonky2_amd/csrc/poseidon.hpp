@@ -9,6 +9,7 @@
 // (scalar loads).  Values stay "lazy" (any u64 congruent to the element) through
 // the 30 rounds and are canonicalised once at the end.
 #pragma once
+#include <utility>
 #include "gl64.hpp"
 
 namespace lcp2 {
@@ -266,21 +267,106 @@ __device__ __forceinline__ void pos_fold_h(u64 al, u64 ah, u32 &r0, u32 &r1) {
   r1 = (u32)(q >> 32);
 }
 
-// state <- MDS(state) + add[0..12) ; add = the next round's constants (or nullptr): the constants ride in the
-// initial value of the accumulators, so the add-round-constant layer costs nothing.
+// One row of the MDS layer: al = k_lo + sum_i lo_i C_i, ah = k_hi + sum_i hi_i C_i as 24 v_mad_u64_u32 with the constants inline, the
+// two chains interleaved.  Left to itself hipcc turns the constants 2, 8 and 16 into 64-bit shift-adds, for which the element has to be
+// zero-extended into a register pair (two moves and a VOP3 op instead of one multiply-add), and it adds the round constant with a separate
+// 64-bit add at the END of each chain; here the wave-uniform round constant is the addend of the FIRST multiply-add (an SGPR pair: one
+// constant-bus read next to the inline constant).  One asm statement per row: between separate statements hipcc pads every dependent
+// pair with a wait state it cannot know to be unnecessary.  x0..x11: the row's elements in the order of the circulant's constants
+// 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20 (row 0: 25 first - the diagonal's 8).
+#define LCP2_POS_ROW_OPERANDS                                                                                                        \
+  : "=&v"(al), "=&v"(ah)                                                                                                             \
+  : "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]), "v"(l[4]), "v"(l[5]), "v"(l[6]), "v"(l[7]), "v"(l[8]), "v"(l[9]), "v"(l[10]), "v"(l[11]), \
+    "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(h[4]), "v"(h[5]), "v"(h[6]), "v"(h[7]), "v"(h[8]), "v"(h[9]), "v"(h[10]), "v"(h[11]), \
+    "s"(klo), "s"(khi)                                                                                                               \
+  : "vcc"
+template <bool ROW0>
+__device__ __forceinline__ void pos_mds_row(const u32 (&l)[12], const u32 (&h)[12], u64 klo /* wave-uniform */, u64 khi, u64 &al, u64 &ah) {
+  if constexpr (ROW0) {
+    asm(
+        "v_mad_u64_u32 %0, vcc, %2, 25, %26\n\t"
+        "v_mad_u64_u32 %1, vcc, %14, 25, %27\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+        LCP2_POS_ROW_OPERANDS);
+  } else {
+    asm(
+        "v_mad_u64_u32 %0, vcc, %2, 17, %26\n\t"
+        "v_mad_u64_u32 %1, vcc, %14, 17, %27\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, 15, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %15, 15, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, 41, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %16, 41, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, 16, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %17, 16, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %6, 2, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %18, 2, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, 28, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %19, 28, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %8, 13, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %20, 13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %9, 13, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %21, 13, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %10, 39, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %22, 39, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, 18, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %23, 18, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %12, 34, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %24, 34, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %13, 20, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %25, 20, %1"
+        LCP2_POS_ROW_OPERANDS);
+  }
+}
+#undef LCP2_POS_ROW_OPERANDS
+
+// x * C + k with the wave-uniform k as the addend of the multiply-add (C inline): the first term of an accumulator chain whose other
+// constants are too large to be inline (the grouped partial rounds): saves the separate 64-bit add of k
+template <u32 C>
+__device__ __forceinline__ u64 pos_mac_first(u32 x, u64 k /* wave-uniform */) {
+  static_assert(C <= 64, "inline constants only");
+  u64 r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "n"(C), "s"(k) : "vcc");
+  return r;
+}
+template <class F, int... I>
+__device__ __forceinline__ void pos_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void pos_static_for(F &&f) { pos_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// state <- MDS(state) + add[0..12) ; add = the next round's constants, WAVE-UNIFORM (or nullptr): the constants ride in the
+// first multiply-add of the accumulators, so the add-round-constant layer costs nothing.
 __device__ __forceinline__ void pos_mds_h(u32 lo[12], u32 hi[12], const u64 *__restrict__ add) {
-  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u32 nl[12], nh[12];
 #pragma unroll
   for (int r = 0; r < 12; r++) {
-    u64 al = 0, ah = 0;
-    if (add) { const u64 k = add[r]; al = (u32)k; ah = k >> 32; }
+    const u64 k = add ? add[r] : 0;
+    u32 l[12], h[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-      al += (u64)lo[(i + r) % 12] * C[i];
-      ah += (u64)hi[(i + r) % 12] * C[i];
-    }
-    if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
+    for (int i = 0; i < 12; i++) { l[i] = lo[(i + r) % 12]; h[i] = hi[(i + r) % 12]; }
+    u64 al, ah;
+    if (r == 0) pos_mds_row<true>(l, h, (u64)(u32)k, k >> 32, al, ah);
+    else pos_mds_row<false>(l, h, (u64)(u32)k, k >> 32, al, ah);
     pos_fold_h(al, ah, nl[r], nh[r]);
   }
 #pragma unroll
@@ -296,47 +382,46 @@ __device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts
   constexpr PosPartialTables T = pos_partial_tables();
   u32 w0l = lo[0], w0h = hi[0], w1l, w1h, w2l, w2h;
   pos_sbox_h(w0l, w0h);
-  {
+  {  // u1 = row 0 of the MDS layer on (w0, y): constants 25, 15, 41, 16, 2, ... all inline (pos_mds_row)
     const u64 c = kc[0];
-    u64 al = (u32)c, ah = c >> 32;
+    u32 l[12], h[12];
+    l[0] = w0l; h[0] = w0h;
 #pragma unroll
-    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.a[j]; ah += (u64)hi[1 + j] * T.a[j]; }
-    al += (u64)w0l * T.m00; ah += (u64)w0h * T.m00;
+    for (int j = 1; j < 12; j++) { l[j] = lo[j]; h[j] = hi[j]; }
+    u64 al, ah;
+    pos_mds_row<true>(l, h, (u64)(u32)c, c >> 32, al, ah);
     pos_fold_h(al, ah, w1l, w1h);
     next_w(1, w1l, w1h);
   }
-  {
+  {  // the round constant rides in the multiply-add of the one term with an inline constant (m00 = 25)
     const u64 c = kc[1];
-    u64 al = (u32)c, ah = c >> 32;
+    u64 al = pos_mac_first<T.m00>(w1l, (u64)(u32)c), ah = pos_mac_first<T.m00>(w1h, c >> 32);
 #pragma unroll
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA[j]; ah += (u64)hi[1 + j] * T.aA[j]; }
     al += (u64)w0l * T.ab; ah += (u64)w0h * T.ab;
-    al += (u64)w1l * T.m00; ah += (u64)w1h * T.m00;
     pos_fold_h(al, ah, w2l, w2h);
     next_w(2, w2l, w2h);
   }
   u32 nl[12], nh[12];
   {
     const u64 c = kc[2];
-    u64 al = (u32)c, ah = c >> 32;
+    u64 al = pos_mac_first<T.m00>(w2l, (u64)(u32)c), ah = pos_mac_first<T.m00>(w2h, c >> 32);
 #pragma unroll
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA2[j]; ah += (u64)hi[1 + j] * T.aA2[j]; }
     al += (u64)w0l * T.aAb; ah += (u64)w0h * T.aAb;
     al += (u64)w1l * T.ab; ah += (u64)w1h * T.ab;
-    al += (u64)w2l * T.m00; ah += (u64)w2h * T.m00;
     pos_fold_h(al, ah, nl[0], nh[0]);
   }
-#pragma unroll
-  for (int i = 0; i < 11; i++) {
+  pos_static_for<11>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
     const u64 c = kc[3 + i];
-    u64 al = (u32)c, ah = c >> 32;
+    u64 al = pos_mac_first<T.b[i]>(w2l, (u64)(u32)c), ah = pos_mac_first<T.b[i]>(w2h, c >> 32);  // b[i] = M[1 + i][0] <= 41
 #pragma unroll
     for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.A3[i][j]; ah += (u64)hi[1 + j] * T.A3[i][j]; }
     al += (u64)w0l * T.A2b[i]; ah += (u64)w0h * T.A2b[i];
     al += (u64)w1l * T.Ab[i]; ah += (u64)w1h * T.Ab[i];
-    al += (u64)w2l * T.b[i]; ah += (u64)w2h * T.b[i];
     pos_fold_h(al, ah, nl[1 + i], nh[1 + i]);
-  }
+  });
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
 }
