@@ -349,6 +349,57 @@ __device__ __forceinline__ u64 pos_mac_first(u32 x, u64 k /* wave-uniform */) {
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "n"(C), "s"(k) : "vcc");
   return r;
 }
+// Accumulator chains of the grouped partial rounds, whose constants (entries of A^2, A^3 < 2^21) are too large to be inline and sit in
+// SGPRs: the chain is ONE dependent sequence of multiply-adds, the wave-uniform round constant k the addend of the first one (whose
+// constant C0 is inline: two SGPR operands in one instruction are not encodable).  As C, hipcc splits every chain in two, starts both
+// from zero and joins them and k with 64-bit adds.
+template <u32 C0>
+__device__ __forceinline__ u64 pos_chain_first7(u64 k /* wave-uniform */, u32 x0, const u32 (&x)[6], const u32 (&c)[6]) {
+  static_assert(C0 <= 64, "inline constants only");
+  u64 acc;
+  asm(
+      "v_mad_u64_u32 %0, vcc, %1, %8, %15\n\t"
+      "v_mad_u64_u32 %0, vcc, %2, %9, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %3, %10, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %11, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %12, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %13, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %14, %0"
+      : "=&v"(acc)
+      : "v"(x0), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+        "n"(C0), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(k)
+      : "vcc");
+  return acc;
+}
+template <int N>
+__device__ __forceinline__ void pos_chain_add(u64 &acc, const u32 (&x)[N], const u32 (&c)[N]) {
+  static_assert(N == 6 || N == 7, "six or seven terms");
+  if constexpr (N == 6) {
+    asm(
+      "v_mad_u64_u32 %0, vcc, %1, %7, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %2, %8, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %3, %9, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %10, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %11, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %12, %0"
+        : "+v"(acc)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5])
+        : "vcc");
+  } else {
+    asm(
+      "v_mad_u64_u32 %0, vcc, %1, %8, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %2, %9, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %3, %10, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %11, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %12, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %13, %0\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %14, %0"
+        : "+v"(acc)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]),
+          "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6])
+        : "vcc");
+  }
+}
 template <class F, int... I>
 __device__ __forceinline__ void pos_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
@@ -393,34 +444,39 @@ __device__ __forceinline__ void pos_partial3_core(u32 lo[12], u32 hi[12], Consts
     pos_fold_h(al, ah, w1l, w1h);
     next_w(1, w1l, w1h);
   }
-  {  // the round constant rides in the multiply-add of the one term with an inline constant (m00 = 25)
-    const u64 c = kc[1];
-    u64 al = pos_mac_first<T.m00>(w1l, (u64)(u32)c), ah = pos_mac_first<T.m00>(w1h, c >> 32);
-#pragma unroll
-    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA[j]; ah += (u64)hi[1 + j] * T.aA[j]; }
-    al += (u64)w0l * T.ab; ah += (u64)w0h * T.ab;
-    pos_fold_h(al, ah, w2l, w2h);
+  // rows u2, u3 and y3: k + (the S-box output that arrives last) * (inline constant) first, then y[0..6) ; y[6..11) and the earlier S-box outputs
+  auto row = [&](auto c0, u64 k, u32 xl0, u32 xh0, const u32 (&ca)[6], const u32 (&cb5)[5], u32 cw0, u32 cw1, bool has_w1, u32 &rl, u32 &rh) {
+    constexpr u32 C0 = decltype(c0)::value;
+    const u32 xa_l[6] = {lo[1], lo[2], lo[3], lo[4], lo[5], lo[6]}, xa_h[6] = {hi[1], hi[2], hi[3], hi[4], hi[5], hi[6]};
+    u64 al = pos_chain_first7<C0>((u64)(u32)k, xl0, xa_l, ca), ah = pos_chain_first7<C0>(k >> 32, xh0, xa_h, ca);
+    if (has_w1) {
+      const u32 xb_l[7] = {lo[7], lo[8], lo[9], lo[10], lo[11], w0l, w1l}, xb_h[7] = {hi[7], hi[8], hi[9], hi[10], hi[11], w0h, w1h};
+      const u32 cb[7] = {cb5[0], cb5[1], cb5[2], cb5[3], cb5[4], cw0, cw1};
+      pos_chain_add<7>(al, xb_l, cb);
+      pos_chain_add<7>(ah, xb_h, cb);
+    } else {
+      const u32 xb_l[6] = {lo[7], lo[8], lo[9], lo[10], lo[11], w0l}, xb_h[6] = {hi[7], hi[8], hi[9], hi[10], hi[11], w0h};
+      const u32 cb[6] = {cb5[0], cb5[1], cb5[2], cb5[3], cb5[4], cw0};
+      pos_chain_add<6>(al, xb_l, cb);
+      pos_chain_add<6>(ah, xb_h, cb);
+    }
+    pos_fold_h(al, ah, rl, rh);
+  };
+  {
+    const u32 ca[6] = {T.aA[0], T.aA[1], T.aA[2], T.aA[3], T.aA[4], T.aA[5]}, cb5[5] = {T.aA[6], T.aA[7], T.aA[8], T.aA[9], T.aA[10]};
+    row(std::integral_constant<u32, T.m00>{}, kc[1], w1l, w1h, ca, cb5, T.ab, 0, false, w2l, w2h);
     next_w(2, w2l, w2h);
   }
   u32 nl[12], nh[12];
   {
-    const u64 c = kc[2];
-    u64 al = pos_mac_first<T.m00>(w2l, (u64)(u32)c), ah = pos_mac_first<T.m00>(w2h, c >> 32);
-#pragma unroll
-    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.aA2[j]; ah += (u64)hi[1 + j] * T.aA2[j]; }
-    al += (u64)w0l * T.aAb; ah += (u64)w0h * T.aAb;
-    al += (u64)w1l * T.ab; ah += (u64)w1h * T.ab;
-    pos_fold_h(al, ah, nl[0], nh[0]);
+    const u32 ca[6] = {T.aA2[0], T.aA2[1], T.aA2[2], T.aA2[3], T.aA2[4], T.aA2[5]}, cb5[5] = {T.aA2[6], T.aA2[7], T.aA2[8], T.aA2[9], T.aA2[10]};
+    row(std::integral_constant<u32, T.m00>{}, kc[2], w2l, w2h, ca, cb5, T.aAb, T.ab, true, nl[0], nh[0]);
   }
   pos_static_for<11>([&](auto ii) {
     constexpr int i = decltype(ii)::value;
-    const u64 c = kc[3 + i];
-    u64 al = pos_mac_first<T.b[i]>(w2l, (u64)(u32)c), ah = pos_mac_first<T.b[i]>(w2h, c >> 32);  // b[i] = M[1 + i][0] <= 41
-#pragma unroll
-    for (int j = 0; j < 11; j++) { al += (u64)lo[1 + j] * T.A3[i][j]; ah += (u64)hi[1 + j] * T.A3[i][j]; }
-    al += (u64)w0l * T.A2b[i]; ah += (u64)w0h * T.A2b[i];
-    al += (u64)w1l * T.Ab[i]; ah += (u64)w1h * T.Ab[i];
-    pos_fold_h(al, ah, nl[1 + i], nh[1 + i]);
+    const u32 ca[6] = {T.A3[i][0], T.A3[i][1], T.A3[i][2], T.A3[i][3], T.A3[i][4], T.A3[i][5]},
+              cb5[5] = {T.A3[i][6], T.A3[i][7], T.A3[i][8], T.A3[i][9], T.A3[i][10]};
+    row(std::integral_constant<u32, T.b[i]>{}, kc[3 + i], w2l, w2h, ca, cb5, T.A2b[i], T.Ab[i], true, nl[1 + i], nh[1 + i]);  // b[i] = M[1 + i][0] <= 41
   });
 #pragma unroll
   for (int r = 0; r < 12; r++) { lo[r] = nl[r]; hi[r] = nh[r]; }
