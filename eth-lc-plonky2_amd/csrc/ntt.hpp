@@ -91,16 +91,39 @@ LCP2_HD u32 ntt_lds_words(u32 L) { return (1u << L) + ((1u << L) >> 4) + 1; }
 // subtraction.  tests/emu and the GPU parity tests compare the transforms with the oracle's textbook radix-2 NTT.
 //   forward  w^k : k=1 -2^60  k=2 -2^24  k=3 2^84   k=4  2^48  k=5  2^12  k=6 -2^72  k=7 -2^36
 //   inverse w^-k : k=1  2^36  k=2  2^72  k=3 -2^12  k=4 -2^48  k=5 -2^84  k=6  2^24  k=7  2^60
+// The butterfly's canonical a + b and a - b.  Device: a - b is four instructions (the borrow selects -15, and v_mad_i64_i32 adds
+// -15 * 0x11111111 = -(2^32 - 1): the difference + p mod 2^64; see gl64.hpp on the instruction classes) against hipcc's six, and
+// a + b = a - (p - b) shares the form: ten instructions per butterfly instead of twelve.  (b = 0: p - b = p is not canonical; a - p
+// borrows for every canonical a and the correction returns a.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u64 ntt_sub(u64 a, u64 b) {
+  u32 d0, d1, sel;
+  asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %2, 0, -15, vcc"
+      : "=&v"(d0), "=&v"(d1), "=v"(sel) : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)) : "vcc");
+  u64 d = ((u64)d1 << 32) | d0;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(d) : "v"(sel), "s"(0x11111111u) : "vcc");
+  return d;
+}
+__device__ __forceinline__ u64 ntt_add(u64 a, u64 b) { return ntt_sub(a, GL_P - b); }
+#else
+LCP2_HD u64 ntt_sub(u64 a, u64 b) { return gl_sub(a, b); }
+LCP2_HD u64 ntt_add(u64 a, u64 b) { return gl_add(a, b); }
+#endif
+
 // (a - b) * w_16^k
 LCP2_HD u64 ntt_dif_twiddle(u64 a, u64 b, u32 k) {
   switch (k) {
-    case 1: return gl_shl<60>(gl_sub(b, a));
-    case 2: return gl_shl<24>(gl_sub(b, a));
-    case 3: return gl_shl<84>(gl_sub(a, b));
-    case 4: return gl_shl<48>(gl_sub(a, b));
-    case 5: return gl_shl<12>(gl_sub(a, b));
-    case 6: return gl_shl<72>(gl_sub(b, a));
-    default: return gl_shl<36>(gl_sub(b, a));
+    case 1: return gl_shl<60>(ntt_sub(b, a));
+    case 2: return gl_shl<24>(ntt_sub(b, a));
+    case 3: return gl_shl<84>(ntt_sub(a, b));
+    case 4: return gl_shl<48>(ntt_sub(a, b));
+    case 5: return gl_shl<12>(ntt_sub(a, b));
+    case 6: return gl_shl<72>(ntt_sub(b, a));
+    default: return gl_shl<36>(ntt_sub(b, a));
   }
 }
 // (a + x w_16^-k, a - x w_16^-k)
@@ -116,8 +139,8 @@ LCP2_HD void ntt_dit_butterfly(u64 a, u64 x, u32 k, u64 &sum, u64 &diff) {
     case 6: b = gl_shl<24>(x); break;
     default: b = gl_shl<60>(x); break;
   }
-  sum = neg ? gl_sub(a, b) : gl_add(a, b);
-  diff = neg ? gl_add(a, b) : gl_sub(a, b);
+  sum = neg ? ntt_sub(a, b) : ntt_add(a, b);
+  diff = neg ? ntt_add(a, b) : ntt_sub(a, b);
 }
 
 // 2^RB-point transforms on registers.  dif: natural in -> bit-reversed out; dit: bit-reversed in ->
@@ -132,8 +155,8 @@ LCP2_HD void ntt_reg_dif(u64 *x) {
     for (u32 q = 0; q < R / 2; q++) {
       const u32 i = q & (half - 1), i0 = ((q - i) << 1) | i, i1 = i0 + half;
       const u64 a = x[i0], b = x[i1];
-      x[i0] = gl_add(a, b);
-      x[i1] = i ? ntt_dif_twiddle(a, b, i * (8 / half)) : gl_sub(a, b);
+      x[i0] = ntt_add(a, b);
+      x[i1] = i ? ntt_dif_twiddle(a, b, i * (8 / half)) : ntt_sub(a, b);
     }
   }
 }
@@ -151,8 +174,8 @@ LCP2_HD void ntt_reg_dit(u64 *x) {
         ntt_dit_butterfly(a, x[i1], i * (8 / half), x[i0], x[i1]);
       } else {
         const u64 b = x[i1];
-        x[i0] = gl_add(a, b);
-        x[i1] = gl_sub(a, b);
+        x[i0] = ntt_add(a, b);
+        x[i1] = ntt_sub(a, b);
       }
     }
   }
