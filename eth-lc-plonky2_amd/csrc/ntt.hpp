@@ -109,21 +109,65 @@ __device__ __forceinline__ u64 ntt_sub(u64 a, u64 b) {
   return d;
 }
 __device__ __forceinline__ u64 ntt_add(u64 a, u64 b) { return ntt_sub(a, GL_P - b); }
+// canonical form in three instructions: x + 2^32 - 1 carries exactly when x >= p, and then x + (2^32 - 1) mod 2^64 = x - p.  Used by
+// ntt_shl only: after the twiddle multiplies (gl_mul) and at the loads hipcc's four-instruction form stays - with this one there the
+// contiguous pass of the LDE (k_ntt_pass_pf<false, 0, 4>, at its 128-register limit) spills 17 registers.
+__device__ __forceinline__ u64 ntt_canon(u64 x) {
+  u64 t;
+  u32 c;
+  asm("v_mad_u64_u32 %0, vcc, -1, 1, %2\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %1, 0, 1, vcc"
+      : "=&v"(t), "=&v"(c) : "v"(x) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(x) : "v"(c) : "vcc");
+  return x;
+}
+// x * 2^S for canonical x, canonical result: gl_shl (gl64.hpp) with the subtraction above, and for S <= 32 the 96-bit value
+// (x >> (64 - S)) : (x << S) folded with two multiply-adds (hi (2^32 - 1) + lo, its carry times 2^32 - 1 again) and made canonical
+// with a third (x + 2^32 - 1 carries exactly when x >= p): 8 instructions against hipcc's 12
+template <unsigned S>
+__device__ __forceinline__ u64 ntt_shl(u64 x) {
+  static_assert(S > 0 && S < 96 && (S <= 32 || S % 32 != 0), "shift out of range");
+  if constexpr (S <= 32) {
+    u64 r = x << S;
+    const u32 hi = (u32)(x >> (64 - S));
+    u32 c;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %1, 0, 1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, -1, %0"
+        : "+v"(r), "=&v"(c) : "v"(hi) : "vcc");
+    return ntt_canon(r);
+  } else {
+    constexpr unsigned t = S % 32;
+    const u32 y0 = (u32)x << t, y1 = (u32)(x >> (32 - t)), y2 = (u32)(x >> (64 - t));
+    if constexpr (S < 64) {
+      const u32 s = y0 + y1;
+      const u32 carry = s < y0;
+      return ntt_sub(((u64)s << 32) | (u32)(0u - carry), (u64)y1 + y2);
+    } else {
+      return ntt_sub((u64)y0 << 32, ((u64)y2 << 32) + (u64)y1 + (u64)y0);
+    }
+  }
+}
 #else
+LCP2_HD u64 ntt_canon(u64 x) { return gl_canon(x); }
 LCP2_HD u64 ntt_sub(u64 a, u64 b) { return gl_sub(a, b); }
 LCP2_HD u64 ntt_add(u64 a, u64 b) { return gl_add(a, b); }
+template <unsigned S>
+LCP2_HD u64 ntt_shl(u64 x) { return gl_shl<S>(x); }
 #endif
 
 // (a - b) * w_16^k
 LCP2_HD u64 ntt_dif_twiddle(u64 a, u64 b, u32 k) {
   switch (k) {
-    case 1: return gl_shl<60>(ntt_sub(b, a));
-    case 2: return gl_shl<24>(ntt_sub(b, a));
-    case 3: return gl_shl<84>(ntt_sub(a, b));
-    case 4: return gl_shl<48>(ntt_sub(a, b));
-    case 5: return gl_shl<12>(ntt_sub(a, b));
-    case 6: return gl_shl<72>(ntt_sub(b, a));
-    default: return gl_shl<36>(ntt_sub(b, a));
+    case 1: return ntt_shl<60>(ntt_sub(b, a));
+    case 2: return ntt_shl<24>(ntt_sub(b, a));
+    case 3: return ntt_shl<84>(ntt_sub(a, b));
+    case 4: return ntt_shl<48>(ntt_sub(a, b));
+    case 5: return ntt_shl<12>(ntt_sub(a, b));
+    case 6: return ntt_shl<72>(ntt_sub(b, a));
+    default: return ntt_shl<36>(ntt_sub(b, a));
   }
 }
 // (a + x w_16^-k, a - x w_16^-k)
@@ -131,13 +175,13 @@ LCP2_HD void ntt_dit_butterfly(u64 a, u64 x, u32 k, u64 &sum, u64 &diff) {
   u64 b;
   bool neg = false;
   switch (k) {
-    case 1: b = gl_shl<36>(x); break;
-    case 2: b = gl_shl<72>(x); break;
-    case 3: b = gl_shl<12>(x); neg = true; break;
-    case 4: b = gl_shl<48>(x); neg = true; break;
-    case 5: b = gl_shl<84>(x); neg = true; break;
-    case 6: b = gl_shl<24>(x); break;
-    default: b = gl_shl<60>(x); break;
+    case 1: b = ntt_shl<36>(x); break;
+    case 2: b = ntt_shl<72>(x); break;
+    case 3: b = ntt_shl<12>(x); neg = true; break;
+    case 4: b = ntt_shl<48>(x); neg = true; break;
+    case 5: b = ntt_shl<84>(x); neg = true; break;
+    case 6: b = ntt_shl<24>(x); break;
+    default: b = ntt_shl<60>(x); break;
   }
   sum = neg ? ntt_sub(a, b) : ntt_add(a, b);
   diff = neg ? ntt_add(a, b) : ntt_sub(a, b);
