@@ -377,7 +377,7 @@ def standard_gateset():
     ])
 
 
-def synthetic_circuit(params, seed, npi=4, small_values=False, extra=None):
+def synthetic_circuit(params, seed, npi=4, small_values=False, extra=None, coset_shift_base=7):
     """A satisfiable circuit of 2^degree_bits rows over plonky2's own gate set with real copy constraints, laid out the way
     circuit_builder.rs::build lays a circuit out:
       row 0        PublicInputGate: wires 0..4 carry public_inputs_hash
@@ -500,7 +500,7 @@ def synthetic_circuit(params, seed, npi=4, small_values=False, extra=None):
     for cells in pi_cells:
         if len(cells) > 1:
             cycle(cells)
-    k_is = gl.powers(7, NR)
+    k_is = gl.powers(coset_shift_base, NR)  # plonky2: 7^j; any base whose powers lie in distinct cosets of the subgroup serves
     sig = sigma_values(sig_row, sig_col, k_is, params.degree_bits)
     consts = np.concatenate([gs.selector_columns(gate_of_row), c0[None, :], c1[None, :]])
     cs = np.concatenate([consts, sig])

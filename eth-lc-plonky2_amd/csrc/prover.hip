@@ -750,6 +750,8 @@ int stage_quotient_values(lcp2_circuit *c, const u64 *alphas, const u64 *pi_hash
     u64 ls, hs;
     a.points = ntt.shift_table(gl_root_of_unity(lgN), lgN, 0, false, GL_GENERATOR, ls, hs);
     a.k_is = c->d_kis.u(); a.betas = d_betas; a.gammas = d_gammas; a.alphas = d_alphas; a.pis = d_small + SMALL_PI_HASH; a.imm = c->d_imm.u();
+    a.kis_pow7 = 1;
+    for (u32 j = 0; j < NR; j++) a.kis_pow7 &= c->k_is[j] == (j ? gl_mul(c->k_is[j - 1], 7) : 1);  // plonky2's coset shifts
     a.alpha_inv = d_small + SMALL_ALPHA_INV; a.gate_scale = d_small + SMALL_GATE_SCALE; a.alpha_pow = d_small + SMALL_ALPHA_POW;
     a.alpha_limbs = (const u32 *)c->alpha_limbs.p;
     a.code = (const u32 *)c->d_code.p; a.gates = (const GateDev *)c->d_gates.p; a.out = c->qvals.u();

@@ -54,6 +54,7 @@ struct QuotientArgs {
   const u64 *zh_inv;  // 1 / Z_H per top-bits block of the leaf index, [2^rate_bits]
   TwoLevelTable points;  // 7 * w_N^j
   const u64 *k_is, *betas, *gammas, *alphas, *pis, *imm;  // pis: public_inputs_hash[4]
+  u32 kis_pow7;            // k_is[j] = 7^j (plonky2's get_unique_coset_shifts): beta x k_j is carried from wire to wire with a multiply by 7
   // forward-emitting gates (LCP2_GATE_EMIT_FORWARD): sum_i alpha^i c_i = alpha^(m-1) * Horner(c_0 .. c_{m-1}; 1/alpha)
   const u32 *stage_list;   // LDG column lists: entry < num_wires: wire column, else constants column (entry - num_wires)
   u32 num_wires;

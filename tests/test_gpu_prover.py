@@ -32,6 +32,27 @@ def _first_mismatch(m, params, a, b):
 
 # 14-16: the LDE (2^17 .. 2^19 points) and the quotient iNTT run as two passes (strided + contiguous), the FRI schedule has
 # 3 layers, the scans span several blocks: the multi-pass paths of the headline size inside a whole proof
+
+
+def test_other_coset_shifts_take_the_general_path(gpu_ctx, oracle):
+    """plonky2's coset shifts are k_j = 7^j and the permutation pass of K6 carries beta x k_j from wire to wire with a multiply by 7
+    (QuotientArgs.kis_pow7); a description with other shifts (49^j here) must take the general multiply and still give the oracle's proof"""
+    import eth_lc_plonky2_amd as m
+    params = m.standard_params(10, 4)
+    for base in (49, 7):
+        circ, wires, pis = m.circuit.synthetic_circuit(params, seed=77, coset_shift_base=base)
+        assert int(circ.k_is[1]) == base
+        oc = oracle_lib.OracleCircuit(oracle, circ)
+        assert oc.check_witness(wires, pis)[0] == 0
+        want = oc.prove(wires, pis)
+        data = m.CircuitData.build(gpu_ctx, circ)
+        got = data.prove(wires, pis)
+        assert _first_mismatch(m, params, got, want) is None, (base, _first_mismatch(m, params, got, want))
+        data.verify(got, pis)
+        data.close()
+        oc.close()
+
+
 @pytest.mark.parametrize("degree_bits", [5, 6, 8, 10, 12, 13, 14, 15, 16])
 def test_proof_equals_oracle(gpu_ctx, oracle, degree_bits):
     import eth_lc_plonky2_amd as m
