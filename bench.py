@@ -454,7 +454,7 @@ def cpu_baseline(m, ctx, sample_bits, degree_bits):
     try:  # the measured full-size points (separate runs on the GPU box's host, committed: not of this run)
         f = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_full_size.json")))
         full = {"plonky2_gate_set": {
-            "source": "profiles/r04_parity_full_size.json (tools/parity_full_size.py: the oracle's prove() at 2^%d rows on %d threads, the GPU proof of the same "
+            "source": "profiles/r04_parity_full_size.json (tests/checks/parity_full_size.py: the oracle's prove() at 2^%d rows on %d threads, the GPU proof of the same "
                       "witness compared word for word)" % (f["degree_bits"], f["threads"]),
             "oracle_prove_s": f["oracle_prove_s"], "proofs_per_hour": 3600.0 / f["oracle_prove_s"], "gpu_proof_equal": f["gpu_proof_equal"]}}
         g = json.load(open(os.path.join(ROOT, "profiles", "r04_real_gadget_parity.json")))["headline_circuit_2p22"]

@@ -4,14 +4,14 @@ This measures the oracle at 2^18 AND at 2^20 (about 2.5 minutes on the box's 32 
 the model to the 2^18 sample and writes both next to each other: profiles/r04_cpu_baseline_scaling.json.  The GPU proves both samples
 too and the proofs are compared word for word (`gpu_proof_equal`): whole-proof parity at 2^20 rows, which the default bench run stops
 short of (2^18).
-    python3 tools/cpu_baseline_scaling.py [big_bits=20] > gpurun_out/cpu_scaling.json"""
+    python3 tests/checks/cpu_baseline_scaling.py [big_bits=20] > gpurun_out/cpu_scaling.json"""
 import ctypes
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

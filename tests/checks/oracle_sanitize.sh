@@ -3,7 +3,7 @@
 # into /tmp/liboracle_asan.so and runs the oracle-only tests against it (golden vectors, Poseidon / NTT / field checks, small
 # proofs through the oracle's prover and both verifiers).  GPU sanitizers are not available on the pool; this is the CPU half.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 gcc -O1 -g -fPIC -shared -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -o /tmp/liboracle_asan.so oracle/*.c -lm
 export LCP2_ORACLE_LIB=/tmp/liboracle_asan.so
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"

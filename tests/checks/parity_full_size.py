@@ -2,7 +2,7 @@
 """Whole-proof parity at the headline size: the CPU oracle (oracle/, 32 OpenMP threads, ~10 minutes of prove() at 2^22 rows plus its
 build()) and the GPU prove the same 2^22-row circuit of plonky2's gate set from the same witness, and the two proofs are compared word
 for word.  Too long for the test-suite and for bench.py (whose cpu_baseline leg does the same at 2^18); run once per round on the GPU box:
-    python3 tools/parity_full_size.py [bits=22] [plonky2|reference-mix] > gpurun_out/parity_full_size.json
+    python3 tests/checks/parity_full_size.py [bits=22] [plonky2|reference-mix] > gpurun_out/parity_full_size.json
 `reference-mix`: the reference's own gate set (u32_gates.reference_mix_circuit: plonky2_u32 / comparison gates on the GENERATED native
 evaluators of the device, interpreted gate programs in the oracle).
 A heartbeat line goes to stderr every minute (the box takes a silent command for hung)."""
@@ -13,7 +13,7 @@ import sys
 import threading
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

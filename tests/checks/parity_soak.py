@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off robustness run (GPU): many seeds and sizes of GPU-vs-oracle parity beyond what the test-suite pins down:
 whole proofs (synthetic circuits, random and small-valued witnesses), 2^20 random Poseidon permutations, LDE of random columns.
-    python tools/parity_soak.py [rounds]"""
+    python tests/checks/parity_soak.py [rounds]"""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ import numpy as np
 
 os.environ.setdefault("OMP_NUM_THREADS", "16")  # the oracle's OpenMP regions: a GPU box shows more hardware threads than the job may use
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import eth_lc_plonky2_amd as m  # noqa: E402

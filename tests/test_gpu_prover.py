@@ -329,7 +329,7 @@ def test_native_gate_claim_is_checked_at_build(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("round_", range(8))
 def test_parity_soak_seeds(gpu_ctx, oracle, round_):
-    """tools/parity_soak.py folded into the suite: further seeds and sizes, random and small-valued witnesses, and a second
+    """tests/checks/parity_soak.py folded into the suite: further seeds and sizes, random and small-valued witnesses, and a second
     proof on the same handle (workspace reuse)."""
     import eth_lc_plonky2_amd as m
     db = 5 + (round_ * 3) % 9

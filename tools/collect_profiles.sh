@@ -25,7 +25,7 @@ python3 tools/reference_mix_probe.py 22 2 --interpreted > $out/mix_interpreted.j
 for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal.log || exit 1; done && \
 for rw in 0/2 0/4 0/8 5/8; do python3 tools/sharded_proof_demo.py --degree-bits 22 --reps 3 --sharded-columns --row-exchange --chunked --rehearse $rw 2>&1 | grep rehearsal >> $out/sharded_rehearsal_chunked.log || exit 1; done && \
 python3 bench.py --force-sharded --no-cpu-baseline --no-real-gadgets --no-synthetic > $out/bench_force_sharded.json 2> $out/bench_force_sharded.err && \
-python3 tools/cpu_baseline_scaling.py 20 > $out/cpu_baseline_scaling.json 2> $out/cpu_baseline_scaling.err && \
+python3 tests/checks/cpu_baseline_scaling.py 20 > $out/cpu_baseline_scaling.json 2> $out/cpu_baseline_scaling.err && \
 python3 bench.py > $out/bench.json 2> $out/bench.err && \
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/mulchain tools/ubench/mulchain.hip > /dev/null 2>&1 && \
 for w in 2 4 8; do /tmp/mulchain $w || exit 1; done > $out/ubench_mulchain.txt

@@ -4,7 +4,8 @@ U32RangeCheck / U32Subtraction / Comparison rows next to BaseSum, Arithmetic, Co
 inputs hashed in-circuit) at 2^bits rows, witness resident in HBM; prints ONE JSON line with the per-kernel-family times of the last
 `reps` proofs.  bench.py imports measure() for config.reference_gate_set_2p22; under rocprofv3 the same script gives the kernel
 stats / FETCH_SIZE passes of profiles/r04_reference_mix_*.
-    python3 tools/reference_mix_probe.py 22 3 [--interpreted] [--oracle]     (--oracle: also compare with the oracle's proof, small sizes)"""
+    python3 tools/reference_mix_probe.py 22 3 [--interpreted]
+(the comparison with the oracle's proof of this circuit, at 2^20 and 2^22 rows, is tests/checks/parity_full_size.py N reference-mix)"""
 import json
 import os
 import sys
@@ -30,7 +31,7 @@ def generated_gate_registers():
     return regs or None
 
 
-def measure(ctx, degree_bits=22, reps=3, native=True, seed=3, compare_with_oracle=False):
+def measure(ctx, degree_bits=22, reps=3, native=True, seed=3):
     import numpy as np
     import torch
     import eth_lc_plonky2_amd as m
@@ -65,13 +66,6 @@ def measure(ctx, degree_bits=22, reps=3, native=True, seed=3, compare_with_oracl
            "kernel_ms_per_proof": {k: round((p1[k]["ms"] - p0[k]["ms"]) / reps, 3) for k in p1 if p1[k]["launches"] - p0[k]["launches"]},
            "quotient_ms": round((p1["quotient"]["ms"] - p0["quotient"]["ms"]) / reps, 3),
            "description_s": round(t_desc, 1), "build_s": round(t_build, 1)}
-    if compare_with_oracle:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib
-        oc = oracle_lib.OracleCircuit(oracle_lib.load(), circ)
-        want = oc.prove(wires, pis)
-        out["gpu_proof_equals_oracle_proof"] = bool((want == proof).all())
-        oc.close()
     data.close()
     del w
     torch.cuda.empty_cache()
@@ -86,7 +80,7 @@ if __name__ == "__main__":
     reps = int(args[1]) if len(args) > 1 else 3
     torch.cuda.set_device(0)
     ctx = m.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    out = measure(ctx, bits, reps, native="--interpreted" not in sys.argv, compare_with_oracle="--oracle" in sys.argv)
+    out = measure(ctx, bits, reps, native="--interpreted" not in sys.argv)
     if "--interpreted" not in sys.argv and "--no-regs" not in sys.argv:  # (no child process under rocprofv3)
         out["generated_gate_kernels"] = generated_gate_registers()
     print(json.dumps(out))
