@@ -31,7 +31,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # LCP2_ORACLE_LIB: another build of the same sources (tools/oracle_sanitize.sh: AddressSanitizer + UBSan)
+    # LCP2_ORACLE_LIB: another build of the same sources (tests/checks/oracle_sanitize.sh: AddressSanitizer + UBSan)
     L = c.CDLL(os.environ.get("LCP2_ORACLE_LIB") or build())
     V = c.c_void_p
     sig = {
