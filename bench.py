@@ -57,7 +57,7 @@ VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9
 CLOCK_HZ = 2.4e9
 CENSUS = os.path.join(ROOT, "profiles", "r04_poseidon_census.json")  # tools/poseidon_census.py: VALU instructions per permutation as compiled
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of the bench (tools/collect_profiles.sh)
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")  # tools/pmc_traffic.py on the --pmc passes of the bench (tools/collect_profiles.sh)
 REFERENCE_MIX_PMC = os.path.join(ROOT, "profiles", "r04_reference_mix_k6.json")  # tools/k6_profile_summary.py: K6 kernel times and FETCH_SIZE of the reference gate set
 
 
@@ -105,7 +105,7 @@ def leaf_hash_roofline(lh, perms):
     perms_per_s = perms / max(lh["ms"] * 1e-3, 1e-12)
     traffic = pmc_traffic_bytes("k_hash_leaves", per_launch)
     return {"bound": "valu", "kernel": "k_hash_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_from_committed_pmc": True, "traffic_source": "profiles/r03_pmc_traffic.json (ratio of the PMC pass applied to this run's algorithmic bytes)",
+            "traffic": traffic, "traffic_from_committed_pmc": True, "traffic_source": "profiles/r04_pmc_traffic.json (ratio of the PMC pass applied to this run's algorithmic bytes)",
             "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches": lh["launches"],
             "note": "integer-VALU bound (Poseidon): `frac` is the HBM fraction the contract asks for and is legitimately low; `valu` is the bound that binds (DESIGN.md section 3)",
             "valu": valu_roofline(perms_per_s)}
