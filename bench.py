@@ -34,7 +34,8 @@ updates: "replicas", no data-path collective) -> weak scaling; the only collecti
 elapsed time.  After that timed region the ranks (a) prove a batch of 32 updates data-parallel through batch.prove_batch (configs[4]
 as worded: 32 / N per rank, proofs gathered on rank 0) and (b) prove ONE proof together, sharded by LDE coset (BASELINE configs[3];
 eth-lc-plonky2_amd/parallel.py::ShardedProver over RCCL) - reported as `config.batch_of_32` and `config.sharded_proof`; `value` stays
-the replica throughput; a failure of the sharded proof is a non-zero exit code.
+the replica throughput; a failure or a hang of one of these side measurements is reported inside the line (`.error`) and the exit code stays 0
+unless --strict-sharded is given.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing, K4a, integer-VALU bound):
 algorithmic bytes per launch / HIP-event time per launch measured inside this run.  `cpu_baseline` is the oracle (oracle/, kind
@@ -279,9 +280,9 @@ def sharded_proof(m, ctx, circ, cs_ptr, w_dev, pis, rank, world, dist, dev, reps
                            "all_to_all_single: witness values as row blocks; " if rows else "")}
 
 
-def guarded(work, limit_s, on_timeout, exit_fn=os._exit):
+def guarded(work, limit_s, on_timeout, exit_fn=os._exit, exit_code=3):
     """work() under a watchdog: if it has not returned after limit_s seconds, on_timeout(message) runs on the timer thread and the
-    process exits with code 3 (a collective that never completes cannot be interrupted from Python).  The decision "finished" /
+    process exits with `exit_code` (a collective that never completes cannot be interrupted from Python).  The decision "finished" /
     "timed out" is taken once, under a lock: a timer that fires while work() is returning finds the work done and does nothing, and
     the caller does not go on before the timer thread has either exited the process or returned."""
     lock = threading.Lock()
@@ -293,7 +294,7 @@ def guarded(work, limit_s, on_timeout, exit_fn=os._exit):
                 return
             state["done"] = True  # from here on the outcome is the timeout
         on_timeout("did not finish within %s s (a collective hangs?)" % limit_s)
-        exit_fn(3)
+        exit_fn(exit_code)
     timer = threading.Timer(limit_s, give_up)
     timer.daemon = True
     timer.start()
@@ -625,7 +626,10 @@ def main():
             del wires
             return sharded_proof(m, ctx, circ, cs_dev.data_ptr(), w_dev, pis, rank, world, dist, dev)
         try:
-            sharded = guarded(work, limit, lambda why: report({"error": "the sharded proof " + why}, batch, from_watchdog=True))
+            # a hang of this SIDE measurement is reported in the line like an exception of it: the replica result stands and the exit code
+            # stays 0 (a non-zero rank would make the launcher - ours or torch.distributed.run - fail the whole run) unless --strict-sharded
+            sharded = guarded(work, limit, lambda why: report({"error": "the sharded proof " + why}, batch, from_watchdog=True),
+                              exit_code=3 if a.strict_sharded else 0)
         except Exception as e:  # the replica line still goes out and carries the error; --strict-sharded also fails the run
             import traceback
             traceback.print_exc()

@@ -79,6 +79,10 @@ def test_watchdog_does_nothing_when_the_work_finishes_first():
     # (with the real exit_fn the process is gone at that point)
     out = bench.guarded(lambda: time.sleep(0.3) or "late", 0.05, lambda why: events.append(("line", why)), exit_fn=lambda c: events.append(("exit", c)))
     assert out == "late" and [e[0] for e in events] == ["line", "exit"] and events[1][1] == 3
+    # bench.py's default for its side measurement: the line carries the error, the replica result stands, the exit code is 0
+    events.clear()
+    bench.guarded(lambda: time.sleep(0.3), 0.05, lambda why: events.append(("line", why)), exit_fn=lambda c: events.append(("exit", c)), exit_code=0)
+    assert events[1] == ("exit", 0)
     # an exception of the work is the caller's to handle; the watchdog stays quiet
     events.clear()
     try:
