@@ -758,3 +758,102 @@ def test_row_exchange_over_gloo(tmp_path):
     gate-check-verdict all-reduces of ShardedProver.prove(..., row_exchange=True); then the chunked form (chunked=True): 35 wires in
     chunks of 16, 16 and 3 columns, every chunk complete - gathered from both ranks - when it is handed to the commitment, in column order"""
     _run_gloo_pair(tmp_path, _GLOO_ROWS_WORKER)
+
+
+# The chunked coefficient exchange and the collectives' piece-wise forms over FOUR gloo ranks (the 2-rank workers above fix the world
+# size in their stand-ins): chunk_columns / the column-order copies / the row blocks of _commit_wires_chunked with k = 4 columns per
+# rank and chunk and a ragged last chunk (37 wires: 16 + 16 + 5 columns, ranks 2 and 3 bring fewer), and all_to_all_tensor /
+# all_gather_tensor whole, in pieces and staged with four peers.
+_GLOO_WORLD4_WORKER = _GLOO_PRELUDE.replace("world_size=2)", "world_size=4)") + r"""
+import torch
+WORLD, N, W, CH = 4, 8, 37, 2
+ROWS = N // WORLD
+witness = (np.arange(W * N, dtype=np.uint64).reshape(W, N) + np.uint64(9)) * np.uint64(0x10003)
+fc = FakeCtx()
+class FakeLib:
+    def lcp2_ntt_batch(self, handle, ptr, ncols, log_n, inverse, coset, mem):  # stand-in "iNTT": x -> 5 x + 2, in place
+        v = fc._at(ptr.value, ncols * N); v[:] = v * np.uint64(5) + np.uint64(2); return 0
+fc.lib, fc.handle, fc._check = FakeLib(), None, (lambda rc: None)
+class FakeParams:
+    cap_height, num_challenges, rate_bits, degree_bits, num_wires = 4, CH, 3, 3, W
+class FakeCirc:
+    params = FakeParams()
+class ChunkData:
+    def __init__(self, rank): self.rank = rank
+    def commit_wires_rows_begin(self, rows_ptr):
+        rows = fc.buffer_read(rows_ptr, 48 * ROWS).reshape(48, ROWS)[:W]
+        assert (rows == witness[:, ROWS * self.rank:ROWS * (self.rank + 1)]).all(), rows   # this rank's rows of EVERY column, in column order
+        self.seen = []
+    def commit_wires_chunk(self, coeffs_ptr, first_col, ncols):
+        got = fc.buffer_read(coeffs_ptr, ncols * N).reshape(ncols, N)
+        assert (got == witness[first_col:first_col + ncols] * np.uint64(5) + np.uint64(2)).all(), (first_col, got)  # complete when it is absorbed
+        self.seen.append((first_col, ncols))
+    def commit_wires_rows_finish(self):
+        assert self.seen == [(0, 16), (16, 16), (32, 5)], self.seen
+        return np.full((16, 4), 40 + self.rank, dtype=np.uint64)
+class Comm4(m.parallel.TorchComm):  # the library buffers of the stand-in are numpy arrays
+    def _view(self, ptr, words): return torch.from_numpy(fc._at(ptr, words).view(np.int64))
+    def all_gather_device(self, ptr, total_words, words_per_rank):
+        self.all_gather_tensor(self._view(ptr, total_words), rank); self.bytes_gathered += 8 * words_per_rank * (WORLD - 1)
+    def all_to_all_device(self, send_ptr, recv_ptr, words_per_pair):
+        self.all_to_all_tensor(self._view(recv_ptr, WORLD * words_per_pair), self._view(send_ptr, WORLD * words_per_pair))
+        self.bytes_gathered += 8 * words_per_pair * (WORLD - 1)
+sp = object.__new__(m.parallel.ShardedProver)
+sp.b, sp.ctx, sp.circ, sp.rank, sp.world, sp.comm = m.binding, fc, FakeCirc(), rank, WORLD, Comm4(dist)
+sp._vals = sp._coeffs = sp._row_bufs = sp._chunk_bufs = None
+sp.data = ChunkData(rank)
+mine = m.parallel.chunk_columns(W, rank, WORLD)
+assert mine == [c for j in range(3) for c in range(16 * j + 4 * rank, 16 * j + 4 * rank + 4) if c < W], mine
+assert sorted(c for r in range(WORLD) for c in m.parallel.chunk_columns(W, r, WORLD)) == list(range(W))
+steps = sp._commit_wires_chunked(witness[mine].copy(), 0)
+reply = None
+try:  # the dispatch of ShardedProver.prove() for the requests this generator makes
+    while True:
+        req = steps.send(reply)
+        if req[0] == "all_gather_async": reply = sp.comm.all_gather_device(req[1], req[2], req[3])  # gloo: gathered on the spot
+        elif req[0] == "all_to_all_device": reply = sp.comm.all_to_all_device(req[1], req[2], req[3])
+        elif req[0] == "wait": assert req[1] is None; reply = None
+        else: raise SystemExit("unexpected request %r" % (req[0],))
+except StopIteration as done:
+    assert (done.value == 40 + rank).all()
+# received: 3 chunks of 16 columns minus the own 4 per chunk slot (padded slots included), and the other ranks' row blocks
+assert sp.comm.bytes_gathered == 8 * (3 * 12 * N + 3 * 12 * ROWS), sp.comm.bytes_gathered
+# the primitives with four peers: whole, in pieces (per-pair limit, per-call limit), staged
+K = 6
+for pair, call, staged in ((1 << 26, 1 << 27, False), (4, 1 << 27, False), (1 << 26, 8, False), (1 << 26, 1 << 27, True)):
+    cm = Comm4(dist, staged=staged); cm.A2A_WORDS_PER_PAIR, cm.A2A_WORDS_PER_CALL = pair, call
+    snd = torch.arange(WORLD * K, dtype=torch.int64) + 1000 * rank    # part d goes to rank d
+    rcv = torch.zeros(WORLD * K, dtype=torch.int64)
+    cm.all_to_all_tensor(rcv, snd)
+    assert rcv.tolist() == [1000 * s + K * rank + j for s in range(WORLD) for j in range(K)], (pair, call, staged, rcv.tolist())
+for limit, staged in ((1 << 27, False), (4, False), (1 << 27, True)):
+    cm = Comm4(dist, staged=staged); cm.GATHER_WORDS_PER_RANK = limit
+    buf = torch.zeros(WORLD * K, dtype=torch.int64); buf[K * rank:K * rank + K] = torch.arange(K) + 50 * (rank + 1)
+    cm.all_gather_tensor(buf, rank)
+    assert buf.tolist() == [50 * (r + 1) + j for r in range(WORLD) for j in range(K)], (limit, staged, buf.tolist())
+# shares of a 16-entry cap from four ranks (four entries each) and the verdict word
+share = np.zeros((16, 4), dtype=np.uint64); share[4 * rank:4 * rank + 4] = np.uint64(2**63 + 5 + rank)
+full = sp.comm.sum_host(share)
+assert [int(full[4 * r, 0]) for r in range(WORLD)] == [2**63 + 5 + r for r in range(WORLD)]
+assert m.parallel.block_range(rank, WORLD) == (2 * rank, 2)
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_chunked_exchange_over_four_gloo_ranks(tmp_path):
+    """world_size-4 gloo: ShardedProver._commit_wires_chunked (37 wires in chunks of 16, 16 and 5 columns, four columns per rank and chunk,
+    ragged last chunk) with every chunk complete and in column order when it reaches the commitment and every rank holding exactly its own
+    rows of every column; all_to_all_tensor / all_gather_tensor whole, in pieces and staged between four peers"""
+    script = tmp_path / "worker4.py"
+    script.write_text(_GLOO_WORLD4_WORKER)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(4)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o
