@@ -764,9 +764,10 @@ def test_row_exchange_over_gloo(tmp_path):
 # size in their stand-ins): chunk_columns / the column-order copies / the row blocks of _commit_wires_chunked with k = 4 columns per
 # rank and chunk and a ragged last chunk (37 wires: 16 + 16 + 5 columns, ranks 2 and 3 bring fewer), and all_to_all_tensor /
 # all_gather_tensor whole, in pieces and staged with four peers.
-_GLOO_WORLD4_WORKER = _GLOO_PRELUDE.replace("world_size=2)", "world_size=4)") + r"""
+_GLOO_WORLD4_WORKER = _GLOO_PRELUDE.replace("world_size=2)", "world_size=int(sys.argv[4]))") + r"""
 import torch
-WORLD, N, W, CH = 4, 8, 37, 2
+WORLD, N, W, CH = int(sys.argv[4]), 8, 37, 2
+KC = 16 // WORLD   # columns per rank and chunk
 ROWS = N // WORLD
 witness = (np.arange(W * N, dtype=np.uint64).reshape(W, N) + np.uint64(9)) * np.uint64(0x10003)
 fc = FakeCtx()
@@ -803,7 +804,7 @@ sp.b, sp.ctx, sp.circ, sp.rank, sp.world, sp.comm = m.binding, fc, FakeCirc(), r
 sp._vals = sp._coeffs = sp._row_bufs = sp._chunk_bufs = None
 sp.data = ChunkData(rank)
 mine = m.parallel.chunk_columns(W, rank, WORLD)
-assert mine == [c for j in range(3) for c in range(16 * j + 4 * rank, 16 * j + 4 * rank + 4) if c < W], mine
+assert mine == [c for j in range(3) for c in range(16 * j + KC * rank, 16 * j + KC * rank + KC) if c < W], mine
 assert sorted(c for r in range(WORLD) for c in m.parallel.chunk_columns(W, r, WORLD)) == list(range(W))
 steps = sp._commit_wires_chunked(witness[mine].copy(), 0)
 reply = None
@@ -817,7 +818,7 @@ try:  # the dispatch of ShardedProver.prove() for the requests this generator ma
 except StopIteration as done:
     assert (done.value == 40 + rank).all()
 # received: 3 chunks of 16 columns minus the own 4 per chunk slot (padded slots included), and the other ranks' row blocks
-assert sp.comm.bytes_gathered == 8 * (3 * 12 * N + 3 * 12 * ROWS), sp.comm.bytes_gathered
+assert sp.comm.bytes_gathered == 8 * (3 * (16 - KC) * N + 3 * (16 - KC) * ROWS), sp.comm.bytes_gathered
 # the primitives with four peers: whole, in pieces (per-pair limit, per-call limit), staged
 K = 6
 for pair, call, staged in ((1 << 26, 1 << 27, False), (4, 1 << 27, False), (1 << 26, 8, False), (1 << 26, 1 << 27, True)):
@@ -832,28 +833,30 @@ for limit, staged in ((1 << 27, False), (4, False), (1 << 27, True)):
     cm.all_gather_tensor(buf, rank)
     assert buf.tolist() == [50 * (r + 1) + j for r in range(WORLD) for j in range(K)], (limit, staged, buf.tolist())
 # shares of a 16-entry cap from four ranks (four entries each) and the verdict word
-share = np.zeros((16, 4), dtype=np.uint64); share[4 * rank:4 * rank + 4] = np.uint64(2**63 + 5 + rank)
+E = 16 // WORLD
+share = np.zeros((16, 4), dtype=np.uint64); share[E * rank:E * rank + E] = np.uint64(2**63 + 5 + rank)
 full = sp.comm.sum_host(share)
-assert [int(full[4 * r, 0]) for r in range(WORLD)] == [2**63 + 5 + r for r in range(WORLD)]
-assert m.parallel.block_range(rank, WORLD) == (2 * rank, 2)
+assert [int(full[E * r, 0]) for r in range(WORLD)] == [2**63 + 5 + r for r in range(WORLD)]
+assert m.parallel.block_range(rank, WORLD) == (8 // WORLD * rank, 8 // WORLD)
 dist.barrier()
 dist.destroy_process_group()
 print("ok", rank)
 """
 
 
-def test_chunked_exchange_over_four_gloo_ranks(tmp_path):
-    """world_size-4 gloo: ShardedProver._commit_wires_chunked (37 wires in chunks of 16, 16 and 5 columns, four columns per rank and chunk,
-    ragged last chunk) with every chunk complete and in column order when it reaches the commitment and every rank holding exactly its own
-    rows of every column; all_to_all_tensor / all_gather_tensor whole, in pieces and staged between four peers"""
+@pytest.mark.parametrize("world", [4, 8])
+def test_chunked_exchange_over_four_and_eight_gloo_ranks(tmp_path, world):
+    """world_size-4 and -8 gloo: ShardedProver._commit_wires_chunked (37 wires in chunks of 16, 16 and 5 columns, four or two columns per rank and chunk,
+    ragged last chunk, one row per rank at eight) with every chunk complete and in column order when it reaches the commitment and every rank holding exactly its own
+    rows of every column; all_to_all_tensor / all_gather_tensor whole, in pieces and staged between the peers"""
     script = tmp_path / "worker4.py"
     script.write_text(_GLOO_WORLD4_WORKER)
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(4)]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
