@@ -819,6 +819,55 @@ except StopIteration as done:
     assert (done.value == 40 + rank).all()
 # received: 3 chunks of 16 columns minus the own 4 per chunk slot (padded slots included), and the other ranks' row blocks
 assert sp.comm.bytes_gathered == 8 * (3 * (16 - KC) * N + 3 * (16 - KC) * ROWS), sp.comm.bytes_gathered
+# ---- the whole proof over the same ranks: ShardedProver.prove(..., row_exchange=True, chunked=True) with a stand-in for the per-rank compute
+# that checks what each exchange delivers (the complete table of block products, the complete Z / partial-product buffer, complete
+# quotient planes) and returns disjoint shares the way the C ABI does
+NCZ, E = 4, 16 // WORLD
+class ProofData(ChunkData):
+    proof_words = 3 * 64 + 40
+    def __init__(self, rank):
+        self.rank, self.qbuf, self.zbuf = rank, np.zeros(CH * 8 * WORLD, dtype=np.uint64), np.zeros(NCZ * N, dtype=np.uint64)
+        fc.bufs[self.qbuf.ctypes.data], fc.bufs[self.zbuf.ctypes.data] = self.qbuf, self.zbuf   # "device" buffers of the stand-in
+    def _share(self, tag):
+        c = np.zeros((16, 4), dtype=np.uint64)
+        c[E * self.rank:E * self.rank + E] = np.arange(4 * E, dtype=np.uint64).reshape(E, 4) * np.uint64(7) + np.uint64(tag + 100 * self.rank)
+        return c
+    def commit_wires_rows_finish(self):
+        ChunkData.commit_wires_rows_finish(self); return self._share(1)
+    def perm_zs_rows_begin(self, betas, gammas, world):
+        assert world == WORLD
+        out = np.zeros(world * CH, dtype=np.uint64); out[CH * self.rank:CH * self.rank + CH] = [11 + self.rank, 21 + self.rank]; return out
+    def perm_zs_rows_finish(self, products):
+        assert list(products) == [v for r in range(WORLD) for v in (11 + r, 21 + r)]     # every rank's block products
+        z = self.zbuf.reshape(WORLD, NCZ, ROWS); z[self.rank] = np.arange(NCZ * ROWS, dtype=np.uint64).reshape(NCZ, ROWS) + np.uint64(1000 * (self.rank + 1))
+        return self.zbuf.ctypes.data, self.zbuf.size
+    def perm_zs_commit(self):
+        want = np.stack([np.arange(NCZ * ROWS, dtype=np.uint64).reshape(NCZ, ROWS) + np.uint64(1000 * (r + 1)) for r in range(WORLD)])
+        assert (self.zbuf.reshape(WORLD, NCZ, ROWS) == want).all()                        # every rank's rows of the Z columns
+        return self._share(2)
+    def quotient_values(self, alphas, pi_hash):  # this rank's contiguous run of each challenge plane
+        for c in range(CH): self.qbuf[8 * WORLD * c + 8 * self.rank:8 * WORLD * c + 8 * self.rank + 8] = np.uint64(70 + 10 * c + self.rank)
+    def quotient_buffer(self): return (self.qbuf.ctypes.data, self.qbuf.size)
+    def quotient_commit(self):
+        assert self.qbuf.tolist() == [70 + 10 * c + r for c in range(CH) for r in range(WORLD) for _ in range(8)]
+        return self._share(3)
+    def proof_section(self, which): return {0: (192, 8), 1: (200, 8), 2: (192, 40)}[which]
+    def fri_open_begin(self, zeta, state, proof): proof[192 + self.rank % 8] = 5 + self.rank
+    def fri_open_commit(self, proof): proof[200 + self.rank % 8] = 60 + self.rank
+    def fri_open_finish(self, proof):  # like the library: words every rank already holds in full (summed sections) stay on rank 0 only
+        if self.rank: proof[192:208] = 0
+        proof[208 + 3 * self.rank:211 + 3 * self.rank] = 9
+sp.data = ProofData(rank)
+sp.digest = np.arange(4, dtype=np.uint64)
+sp.comm.bytes_gathered = 0
+proof = sp.prove(witness[mine].copy(), np.array([3, 4], dtype=np.uint64), sharded_columns=True, row_exchange=True, chunked=True)
+everyone = [None] * WORLD
+dist.all_gather_object(everyone, proof.tobytes())
+assert all(p == everyone[0] for p in everyone)                                           # one proof on every rank
+assert (proof[:192].reshape(3, 16, 4) != 0).all() and proof[192:192 + WORLD].tolist() == [5 + r for r in range(WORLD)]
+assert proof[200:200 + WORLD].tolist() == [60 + r for r in range(WORLD)] and proof[208:208 + 3 * WORLD].tolist() == [9] * (3 * WORLD)
+# received on top of the coefficient chunks and row blocks: the other ranks' Z rows and their runs of both quotient planes
+assert sp.comm.bytes_gathered == 8 * (3 * (16 - KC) * N + 3 * (16 - KC) * ROWS + NCZ * ROWS * (WORLD - 1) + CH * 8 * (WORLD - 1)), sp.comm.bytes_gathered
 # the primitives with four peers: whole, in pieces (per-pair limit, per-call limit), staged
 K = 6
 for pair, call, staged in ((1 << 26, 1 << 27, False), (4, 1 << 27, False), (1 << 26, 8, False), (1 << 26, 1 << 27, True)):
@@ -833,7 +882,6 @@ for limit, staged in ((1 << 27, False), (4, False), (1 << 27, True)):
     cm.all_gather_tensor(buf, rank)
     assert buf.tolist() == [50 * (r + 1) + j for r in range(WORLD) for j in range(K)], (limit, staged, buf.tolist())
 # shares of a 16-entry cap from four ranks (four entries each) and the verdict word
-E = 16 // WORLD
 share = np.zeros((16, 4), dtype=np.uint64); share[E * rank:E * rank + E] = np.uint64(2**63 + 5 + rank)
 full = sp.comm.sum_host(share)
 assert [int(full[E * r, 0]) for r in range(WORLD)] == [2**63 + 5 + r for r in range(WORLD)]
@@ -848,7 +896,8 @@ print("ok", rank)
 def test_chunked_exchange_over_four_and_eight_gloo_ranks(tmp_path, world):
     """world_size-4 and -8 gloo: ShardedProver._commit_wires_chunked (37 wires in chunks of 16, 16 and 5 columns, four or two columns per rank and chunk,
     ragged last chunk, one row per rank at eight) with every chunk complete and in column order when it reaches the commitment and every rank holding exactly its own
-    rows of every column; all_to_all_tensor / all_gather_tensor whole, in pieces and staged between the peers"""
+    rows of every column; then the WHOLE proof (prove(..., row_exchange=True, chunked=True)): the complete table of block products, the complete Z rows and
+    complete quotient planes reach every rank and all ranks assemble the same proof; all_to_all_tensor / all_gather_tensor whole, in pieces and staged between the peers"""
     script = tmp_path / "worker4.py"
     script.write_text(_GLOO_WORLD4_WORKER)
     import socket
