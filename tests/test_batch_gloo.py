@@ -72,3 +72,14 @@ def test_two_rank_batch_over_gloo(tmp_path, num_updates):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, num_updates, str(tmp_path)), nprocs=2, join=True)
     assert int(np.load(tmp_path / "ok.npy")[0]) == num_updates
+
+
+def test_four_rank_batch_with_an_idle_rank_over_gloo(tmp_path):
+    """6 updates over 4 ranks (2, 2, 1, 1: padded gather blocks) and 3 updates over 4 ranks (the last rank proves nothing and still takes
+    part in the collectives)"""
+    import torch.multiprocessing as mp
+    import oracle_lib
+    oracle_lib.build()
+    for num_updates in (6, 3):
+        mp.spawn(_worker, args=(4, _free_port(), num_updates, str(tmp_path)), nprocs=4, join=True)
+        assert int(np.load(tmp_path / "ok.npy")[0]) == num_updates
