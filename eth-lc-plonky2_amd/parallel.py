@@ -319,9 +319,13 @@ class ShardedProver:
         for t in range(k):
             if count(rank, t):
                 ctx.buffer_copy_2d(cbase + 8 * (rank * k + t) * n, C * n, cown + 8 * t * n, k * n, n, count(rank, t))
+        # What this rank contributes to EVERY chunk is in place now (the copies above), so only the first gather is ordered against the
+        # library's stream; the later ones ("later": the communicator's stream has already waited for that point) do not wait for the chunk
+        # that is being extended when they are issued.  That matters when the host blocks inside a collective (TORCH_NCCL_BLOCKING_WAIT, what
+        # bench.py sets): the gather of chunk j + 2 then runs while chunk j - 1 is still on the device, and chunk j is queued behind it in time.
         handles = []
         for j in range(min(2, nch)):  # two chunks in flight
-            handles.append((yield ("all_gather_async", cbase + 8 * C * j * n, C * n, k * n)))
+            handles.append((yield ("all_gather_async", cbase + 8 * C * j * n, C * n, k * n, "later" if j else "first")))
         # the witness values as row blocks (all-to-all), then into column order
         for dst in range(world):
             if cols:
@@ -335,7 +339,7 @@ class ShardedProver:
         for j in range(nch):
             yield ("wait", handles[j])
             if j + 2 < nch:
-                handles.append((yield ("all_gather_async", cbase + 8 * C * (j + 2) * n, C * n, k * n)))
+                handles.append((yield ("all_gather_async", cbase + 8 * C * (j + 2) * n, C * n, k * n, "later")))
             d.commit_wires_chunk(cbase + 8 * C * j * n, C * j, min(C, W - C * j))
         return d.commit_wires_rows_finish()
 
@@ -352,7 +356,8 @@ class ShardedProver:
                     reply = None
                 elif req[0] == "all_gather_async":  # a communicator without the asynchronous form gathers on the spot
                     start = getattr(self.comm, "all_gather_device_async", None)
-                    reply = start(req[1], req[2], req[3]) if start else self.comm.all_gather_device(req[1], req[2], req[3])
+                    reply = (start(req[1], req[2], req[3], source_ready=len(req) > 4 and req[4] == "later") if start
+                             else self.comm.all_gather_device(req[1], req[2], req[3]))
                 elif req[0] == "wait":
                     if req[1] is not None:
                         self.comm.wait(req[1])
@@ -453,11 +458,13 @@ class TorchComm:
         self.seconds["all_gather"] += time.perf_counter() - t0
         self.bytes_gathered += 8 * words_per_rank * (world - 1)
 
-    def all_gather_device_async(self, ptr, total_words, words_per_rank):
+    def all_gather_device_async(self, ptr, total_words, words_per_rank, source_ready=False):
         """all_gather_device on the communicator's own stream: returns an event; the library's stream (wrapped by its handle,
         lcp2_ctx_stream) goes on with the chunk before.  What this rank contributes was written by work already queued on the library's
-        stream: the side stream waits for it.  (With TORCH_NCCL_BLOCKING_WAIT the HOST blocks inside the call until
-        the collective is done - the kernels queued before it still overlap it.)  Other backends: the synchronous form."""
+        stream: the side stream waits for it - unless the caller says it was complete when an EARLIER asynchronous gather was issued
+        (source_ready: the side stream, being in order, is already behind that point), in which case the gather does not wait for whatever
+        the library's stream has been given since.  (With TORCH_NCCL_BLOCKING_WAIT the HOST blocks inside the call until the collective
+        is done - the kernels queued before it still overlap it.)  Other backends: the synchronous form."""
         import time
         import torch
         if self.dist.get_backend() != "nccl" or self.staged:
@@ -469,9 +476,11 @@ class TorchComm:
             self._side = torch.cuda.Stream(device=self.device)
             self._lib_stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)  # the context's own stream, by handle
         t0 = time.perf_counter()
-        ready = torch.cuda.Event()
-        ready.record(self._lib_stream)
-        self._side.wait_event(ready)
+        if not (source_ready and getattr(self, "_side_ordered", False)):
+            ready = torch.cuda.Event()
+            ready.record(self._lib_stream)
+            self._side.wait_event(ready)
+            self._side_ordered = True  # (a later source_ready gather relies on this wait having been queued on the side stream)
         with torch.cuda.stream(self._side):
             out = torch.as_tensor(_DevicePtr(ptr, total_words), device=self.device)
             self.all_gather_tensor(out, self.dist.get_rank())
