@@ -407,6 +407,8 @@ class TorchComm:
         self.bytes_gathered = 0  # received by this rank through all_gather_device / all_to_all_device (exchange accounting of the bench)
         self.row_exchange_ok = True  # self_check(): the all-to-all of the row exchange form reproduces a known answer
         self.seconds = {"all_gather": 0.0, "all_to_all": 0.0, "all_reduce": 0.0}  # wall time inside the (synchronous) collectives
+        self._side = self._lib_stream = None  # all_gather_device_async: the communication stream and the library's stream, made at the first use
+        self._side_ordered = False            # ... and whether the communication stream has been ordered behind the library's stream yet
 
     def sum_host(self, arr):
         import time
@@ -472,11 +474,11 @@ class TorchComm:
             return None
         world = self.dist.get_world_size()
         assert total_words == words_per_rank * world
-        if getattr(self, "_side", None) is None:
+        if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._lib_stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)  # the context's own stream, by handle
         t0 = time.perf_counter()
-        if not (source_ready and getattr(self, "_side_ordered", False)):
+        if not (source_ready and self._side_ordered):
             ready = torch.cuda.Event()
             ready.record(self._lib_stream)
             self._side.wait_event(ready)
